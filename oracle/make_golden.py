@@ -1,0 +1,163 @@
+"""Generate tests/golden/*.npz + tables.json from the REFERENCE's own class.
+
+Runs only in the build container (needs /root/reference; TEST INFRASTRUCTURE
+ONLY).  The reference's ``helpers/model.py`` imports torchvision at module
+level (model.py:5-9); torchvision is absent here, so empty stand-in modules
+are pre-seeded into ``sys.modules`` for those import lines only --
+``SlowFastLayers`` itself (model.py:30-165) uses nothing but torch and runs
+unmodified.  ``helpers.constants`` is never imported (it has
+import-time side effects).
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+What is stored per case (fp32 unless noted), all from the reference class:
+  out/<clip>/<level>       fused feature map [1,256,H,W] (clip 0 only for big cases)
+  loss/<clip>              proxy loss  sum_levels mean(out^2)
+  stat/<key>               every BN running_mean / running_var / num_batches_tracked
+                           after the two training clips
+  gnorm/<key>, gsamp/<key> L2 norm and 64 strided samples of each parameter's grad
+                           accumulated over the two clips (model.py:369-374 semantics)
+  pnorm/<key>, psamp/<key> the same for each parameter after ONE SGD step
+                           (lr 1e-3, momentum 0.9, wd 1e-4; train.py:80)
+  eval_out/<level>         eval-mode output of clip 0 with the closed-form running stats
+"""
+import json
+import os
+import sys
+import types
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle.closed_form import closed_form_features, closed_form_state_dict, slice_slow  # noqa: E402
+from oracle.slowfast_ref import proxy_loss  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+CONFIGS = [(1, 1), (3, 3), (7, 7), (1, 7), (3, 7), (4, 32), (4, 64)]
+SMALL_LEVELS = OrderedDict([('0', (12, 21)), ('pool', (6, 10))])
+BIG_CASES = {(3, 7): OrderedDict([('0', (24, 42))])}
+NSAMP = 64
+
+
+def import_reference_class():
+    names = ['torchvision', 'torchvision.models', 'torchvision.models.detection',
+             'torchvision.models.detection.faster_rcnn', 'torchvision.models.detection.image_list',
+             'torchvision.models.detection.mask_rcnn']
+    for n in names:
+        sys.modules.setdefault(n, types.ModuleType(n))
+    sys.modules['torchvision.models.detection.faster_rcnn'].FastRCNNPredictor = object
+    sys.modules['torchvision.models.detection.image_list'].ImageList = object
+    sys.modules['torchvision.models.detection.mask_rcnn'].MaskRCNNPredictor = object
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, '/root/reference/code')
+    from helpers.model import SlowFastLayers
+    return SlowFastLayers
+
+
+def sample_idx(numel):
+    return (np.arange(NSAMP, dtype=np.int64) * 7919) % numel
+
+
+def clip_inputs(sp, fp, levels, clip):
+    zero = (0,) if (clip == 1 and fp > 1) else ()
+    fast = closed_form_features(fp, levels, clip=clip, zero_frames=zero)
+    return [slice_slow(fast, sp)], [fast]
+
+
+def run_case(cls, sp, fp, levels, tag, store_all_clips):
+    torch.manual_seed(0)
+    model = cls(256, torch.device('cpu'), sp, fp)
+    model.load_state_dict(closed_form_state_dict(model))
+    rec = {}
+
+    # eval mode first (does not touch running stats)
+    model.eval()
+    with torch.no_grad():
+        slow, fast = clip_inputs(sp, fp, levels, 0)
+        out = model.temporally_enhance_features(slow, fast)
+    for k, v in out.items():
+        rec['eval_out/%s' % k] = v.numpy().copy()
+
+    # two accumulated training clips, then one SGD step (model.py:369-374, train.py:80)
+    model.train()
+    params = [p for p in model.parameters()]
+    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    opt.zero_grad()
+    for clip in (0, 1):
+        slow, fast = clip_inputs(sp, fp, levels, clip)
+        out = model.temporally_enhance_features(slow, fast)
+        loss = proxy_loss(out)
+        loss.backward()
+        rec['loss/%d' % clip] = np.float32(loss.item())
+        if clip == 0 or store_all_clips:
+            for k, v in out.items():
+                rec['out/%d/%s' % (clip, k)] = v.detach().numpy().copy()
+    for key, p in model.named_parameters():
+        g = p.grad.detach().reshape(-1)
+        rec['gnorm/%s' % key] = np.float32(g.double().norm().item())
+        rec['gsamp/%s' % key] = g[sample_idx(g.numel())].numpy().copy()
+    for key, b in model.named_buffers():
+        rec['stat/%s' % key] = b.detach().numpy().copy()
+    opt.step()
+    for key, p in model.named_parameters():
+        v = p.detach().reshape(-1)
+        rec['pnorm/%s' % key] = np.float32(v.double().norm().item())
+        rec['psamp/%s' % key] = v[sample_idx(v.numel())].numpy().copy()
+    path = os.path.join(GOLDEN, 'sf_%d_%d_%s.npz' % (sp, fp, tag))
+    np.savez_compressed(path, **rec)
+    return path
+
+
+def input_grad_case(cls, sp, fp, levels):
+    """OSVOS-with-trainable-backbone needs dgrad into the inputs
+    (reference code/osvos/osvos_model.py:50,64): pin it for one config."""
+    model = cls(256, torch.device('cpu'), sp, fp)
+    model.load_state_dict(closed_form_state_dict(model))
+    model.train()
+    fast = closed_form_features(fp, levels, clip=0)
+    for v in fast.values():
+        v.requires_grad_(True)
+    out = model.temporally_enhance_features([slice_slow(fast, sp)], [fast])
+    proxy_loss(out).backward()
+    rec = {}
+    for k, v in fast.items():
+        g = v.grad.reshape(-1)
+        rec['ignorm/%s' % k] = np.float32(g.double().norm().item())
+        rec['igsamp/%s' % k] = g[sample_idx(g.numel())].numpy().copy()
+    path = os.path.join(GOLDEN, 'sf_%d_%d_inputgrad.npz' % (sp, fp))
+    np.savez_compressed(path, **rec)
+    return path
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    cls = import_reference_class()
+    tables = {'kernel_sizes': {}, 'param_counts': {}, 'state_dict': {}}
+    for sp, fp in CONFIGS + [(1, 8), (8, 8)]:
+        m = cls(256, torch.device('cpu'), sp, fp)
+        key = '%d-%d' % (sp, fp)
+        tables['kernel_sizes'][key] = {
+            'slow': [m.slow_conv1.kernel_size[0], m.slow_conv2.kernel_size[0], m.slow_conv3.kernel_size[0]],
+            'fast': [m.fast_conv1.kernel_size[0], m.fast_conv2.kernel_size[0], m.fast_conv3.kernel_size[0]],
+            'lateral': [m.conv_f2s1.kernel_size[0], m.conv_f2s2.kernel_size[0]]}
+        tables['param_counts'][key] = int(sum(p.numel() for p in m.parameters()))
+        if (sp, fp) == (3, 7):
+            tables['state_dict'] = OrderedDict((k, [list(v.shape), str(v.dtype)]) for k, v in m.state_dict().items())
+    tables['calc_kernel_sizes'] = {str(p): list(cls._calc_kernel_sizes(None, p)) for p in range(1, 70)}
+    with open(os.path.join(GOLDEN, 'tables.json'), 'w') as f:
+        json.dump(tables, f, indent=1)
+    for sp, fp in CONFIGS:
+        print(run_case(cls, sp, fp, SMALL_LEVELS, 'small', store_all_clips=False), flush=True)
+    for (sp, fp), levels in BIG_CASES.items():
+        print(run_case(cls, sp, fp, levels, 'big', store_all_clips=False), flush=True)
+    print(input_grad_case(cls, 3, 7, SMALL_LEVELS))
+
+
+if __name__ == '__main__':
+    main()
