@@ -1,0 +1,13 @@
+"""sfvos_amd -- MI355X-native SlowFastLayers hot path (hand-written HIP behind a C ABI).
+
+Public surface mirrors the reference's `helpers/model.py` for this path:
+    SlowFastLayers(input_size, device, slow_pathway_size, fast_pathway_size)
+plus the pieces the reference's train.py builds around it (SGD step, gradient averaging for
+one-process-per-GPU data parallelism)."""
+from .plan import SlowFastPlan, calc_fuse_kernel_size, calc_kernel_sizes, davis_pyramid  # noqa: F401
+from .module import SlowFastLayers  # noqa: F401
+from .optim import FusedSGD  # noqa: F401
+from .parallel import GradBucket, init_distributed  # noqa: F401
+
+__all__ = ['SlowFastLayers', 'SlowFastPlan', 'FusedSGD', 'GradBucket', 'init_distributed', 'calc_kernel_sizes',
+           'calc_fuse_kernel_size', 'davis_pyramid']

@@ -1,0 +1,94 @@
+"""ctypes binding of libsfvos.so -- the only path from Python to the HIP kernels.
+
+There is no fallback: if the library is missing or a call fails, a RuntimeError is raised
+(the product must never silently compute on another path)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libsfvos.so')
+
+F32, BF16 = 0, 1
+
+vp, i32, i64, f32, fp = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    """Mirror of sfvos_conv_desc (include/sfvos.h)."""
+    _fields_ = [('dtype', i32), ('batch', i32), ('t_in', i32), ('h', i32), ('w', i32), ('c_in', i32), ('c_out', i32),
+                ('kt', i32), ('taps', i32), ('pad_t', i32), ('ld_x', i32), ('ld_y', i32), ('accumulate', i32),
+                ('x_batch_stride', i64), ('y_batch_stride', i64)]
+
+
+# name -> (restype, argtypes); every symbol include/sfvos.h declares
+SIGNATURES = {
+    'sfvos_version': (i32, []),
+    'sfvos_last_error': (C.c_char_p, []),
+    'sfvos_check_device': (i32, []),
+    'sfvos_frames_to_ndhwc': (i32, [vp, i64, i64, i64, i64, vp, i32, i32, i32, i32, i32, i32, vp]),
+    'sfvos_ndhwc_to_planar': (i32, [vp, i32, vp, i64, i32, i32, vp]),
+    'sfvos_planar_to_ndhwc': (i32, [vp, vp, i32, i64, i32, i32, vp]),
+    'sfvos_ndhwc_to_frames': (i32, [vp, i32, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, vp]),
+    'sfvos_packed_weight_bytes': (C.c_size_t, [i32, i32, i32, i32, i32]),
+    'sfvos_pack_weights_fwd': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    'sfvos_pack_weights_dgrad': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    'sfvos_conv3d_stat_rows': (i32, [C.POINTER(ConvDesc)]),
+    'sfvos_conv3d': (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]),
+    'sfvos_conv3d_wgrad_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
+    'sfvos_conv3d_wgrad': (i32, [C.POINTER(ConvDesc), vp, vp, vp, i32, vp, vp, vp]),
+    'sfvos_bn_finalize': (i32, [vp, i32, i64, vp, vp, f32, i32, vp, vp, vp, vp, vp, vp]),
+    'sfvos_bn_eval_coeffs': (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp]),
+    'sfvos_bn_running_update': (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
+    'sfvos_bn_apply': (i32, [vp, i32, vp, i32, i32, i64, i32, vp, vp, i32, vp]),
+    'sfvos_bn_bwd_rows': (i32, [i64]),
+    'sfvos_bn_bwd_reduce': (i32, [vp, i32, vp, i32, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp]),
+    'sfvos_bn_bwd_finalize': (i32, [vp, i32, i64, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    'sfvos_bn_bwd_apply': (i32, [vp, i32, vp, i32, vp, i32, i32, i64, i32, vp, vp, i32, vp, vp, vp, vp, vp]),
+    'sfvos_reduce_rows': (i32, [vp, i32, i32, vp, i32, vp]),
+    'sfvos_sgd_step': (i32, [vp, vp, vp, i64, f32, f32, f32, i32, vp]),
+    'sfvos_scale': (i32, [vp, i64, f32, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libsfvos.so (once).  Raises RuntimeError -- never falls back -- when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'sfvos_amd: %s not found. Build it with `python __graft_entry__.py` (hipcc, gfx950); '
+            'there is no CPU or PyTorch fallback for the SlowFastLayers kernels.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().sfvos_last_error()
+        raise RuntimeError('libsfvos %s failed (%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point and raise on a non-zero status."""
+    check(getattr(load(), name)(*args), name)
+
+
+# Bumped by anything that rewrites parameters behind autograd's back (FusedSGD); the packed
+# MFMA weight images cached by SlowFastLayers are keyed on it.
+_weight_epoch = [0]
+
+
+def bump_weight_epoch():
+    _weight_epoch[0] += 1
+
+
+def weight_epoch():
+    return _weight_epoch[0]

@@ -1,0 +1,77 @@
+// Shared device/host helpers for libsfvos (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/sfvos.h"
+
+namespace sfvos {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short short4v;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define SFVOS_LDS __attribute__((address_space(3)))
+#define SFVOS_GLOBAL __attribute__((address_space(1)))
+
+// ---- element traits: everything on chip is organised in 16-byte chunks ---------------------
+template <int DT> struct Elt;
+template <> struct Elt<SFVOS_F32> {
+  typedef float type;
+  static constexpr int CE = 4;  // elements per 16-B chunk
+  static __device__ __forceinline__ float to_f32(float v) { return v; }
+  static __device__ __forceinline__ float from_f32(float v) { return v; }
+};
+template <> struct Elt<SFVOS_BF16> {
+  typedef __bf16 type;
+  static constexpr int CE = 8;
+  static __device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
+  static __device__ __forceinline__ __bf16 from_f32(float v) { return (__bf16)v; }
+};
+
+// One MFMA "step" consumes one 16-B chunk per lane of A and of B: lane half h (lane>>5)
+// holds chunk 2*step+h.  bf16: one 32x32x16; f32: four 32x32x2 (element e of both chunks
+// pairs k = {chunk(2s)*4+e, chunk(2s+1)*4+e}); the k-sum is the same set either way.
+template <int DT> struct Mma;
+template <> struct Mma<SFVOS_BF16> {
+  static __device__ __forceinline__ void run(f32x16& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0,
+                                                   0, 0);
+  }
+};
+template <> struct Mma<SFVOS_F32> {
+  static __device__ __forceinline__ void run(f32x16& acc, const u32x4& a, const u32x4& b) {
+    f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc, 0, 0, 0);
+  }
+};
+
+// async global -> LDS copy of 16 B per lane; LDS destination = wave-uniform base + lane*16.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const SFVOS_GLOBAL void*)gsrc, (SFVOS_LDS void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ u32x4 lds_read16(const void* p) { return *(const u32x4*)p; }
+
+// ---- host side -------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+#define SFVOS_REQUIRE(cond, ...)   \
+  do {                             \
+    if (!(cond)) {                 \
+      sfvos::set_error(__VA_ARGS__); \
+      return SFVOS_E_ARG;          \
+    }                              \
+  } while (0)
+
+}  // namespace sfvos

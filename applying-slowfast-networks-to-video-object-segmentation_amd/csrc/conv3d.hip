@@ -1,0 +1,355 @@
+// conv3d.hip -- kt x 3 x 3 (pad 0,1,1) and k x 1 x 1 3D convolution, NDHWC, as an implicit GEMM
+// on the gfx950 matrix cores.  Replaces aten::convolution at reference
+// code/helpers/model.py:112,120,124,132,136,144,147; with a flipped weight image and
+// pad_t = kt-1 the same kernel is aten::convolution_backward's grad_input.
+//
+// Decomposition (one workgroup = 8 waves, 2 per SIMD):
+//   output tile  = TT output frames x (TH x 16) pixels x BN output channels
+//   K loop       = stages (input frame t, 64-byte channel chunk cc, spatial tap)
+//   per stage    : the (TH+2)x18 halo tile of frame t / chunk cc sits in LDS (re-used by the 9
+//                  taps and by every output frame t feeds: dt = t - t_out), and the weight
+//                  slice W[dt_lo..dt_hi][tap][cc][BN] is streamed next to it.
+//   staging      : global_load_lds (LDS-DMA) 16 B per lane, double-buffered, one barrier per stage.
+//   LDS images   : chunk-major [16B chunk j][row][col] / [dt][j][n] so every ds_read_b128 of an
+//                  MFMA operand touches 16 consecutive 16-B slots per lane group: conflict-free.
+//   MFMA         : A = 32 pixels (2 rows x 16) x 16B-chunk pair, B = weights; f32 accumulate.
+//   epilogue     : + bias, optional += y, store as dtype, per-channel (sum, sumsq) of the tile
+//                  written as one deterministic partial row per workgroup (BN statistics).
+#include "common.h"
+
+namespace sfvos {
+
+struct ConvArgs {
+  const char* x;
+  const char* wp;
+  const float* bias;
+  char* y;
+  float* stat_part;
+  const char* zeros;
+  int t_in, t_out, H, W, c_in, c_out, kt, pad_t, ld_x, ld_y, accumulate;
+  int tiles_w, tiles_h, t_blocks, n_blocks;
+  long long x_bs, y_bs;
+};
+
+template <int DT, int TAPS, int TT, int MT, int NT, int WS, int WN>
+struct ConvCfg {
+  static constexpr int NWAVES = WS * WN, NTHREADS = 64 * NWAVES;
+  static constexpr int TH = 2 * WS * MT, TW = 16;
+  static constexpr int HALO = (TAPS == 9) ? 1 : 0;
+  static constexpr int HR = TH + 2 * HALO;
+  static constexpr int HC = TW + 2 * HALO;
+  static constexpr int PW = (TAPS == 9) ? 32 : 16;  // row pitch in 16-B slots, multiple of 16
+  static constexpr int BN = WN * NT * 32;
+  static constexpr int X_SLOTS = 4 * HR * PW;
+  static constexpr int X_BYTES = X_SLOTS * 16;
+  static constexpr int W_BYTES = TT * 4 * BN * 16;
+  static constexpr int LDS_BYTES = 2 * X_BYTES + 2 * W_BYTES;
+};
+
+template <int DT, int TAPS, int TT, int MT, int NT, int WS, int WN>
+__global__ __launch_bounds__(64 * WS * WN) void conv3d_kernel(ConvArgs a) {
+  typedef ConvCfg<DT, TAPS, TT, MT, NT, WS, WN> C;
+  typedef typename Elt<DT>::type T;
+  constexpr int CE = Elt<DT>::CE, CK = 4 * CE, ES = 16 / CE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const xbase = smem;
+  char* const wbase = smem + 2 * C::X_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ws = wv % WS, wn = wv / WS;
+  const int r = lane & 31, hh = lane >> 5;
+
+  int bid = blockIdx.x;
+  const int tw = bid % a.tiles_w; bid /= a.tiles_w;
+  const int th = bid % a.tiles_h; bid /= a.tiles_h;
+  const int nb = bid % a.n_blocks; bid /= a.n_blocks;
+  const int tb = bid % a.t_blocks; bid /= a.t_blocks;
+  const int b = bid;
+  const int h0 = th * C::TH, w0 = tw * C::TW, n0 = nb * C::BN, tb0 = tb * TT;
+  const int tt_eff = min(TT, a.t_out - tb0);
+
+  const int t_lo = max(0, tb0 - a.pad_t);
+  const int t_hi = min(a.t_in - 1, tb0 + tt_eff - 1 - a.pad_t + a.kt - 1);
+  const int n_tin = max(0, t_hi - t_lo + 1);
+  const int ncc = a.c_in / CK;
+  const int S = n_tin * ncc * TAPS;
+
+  const char* xclip = a.x + (long long)b * a.x_bs * ES;
+
+  f32x16 acc[TT][MT][NT];
+#pragma unroll
+  for (int j = 0; j < TT; ++j)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][i][q][e] = 0.f;
+
+  // ---- stage issue: LDS-DMA of the weight slice (+ halo tile when tap == 0) -------------------
+  auto issue = [&](int ti, int cc, int tap, int s) {
+    const int t = t_lo + ti;
+    const int dt_hi = min(a.kt - 1, t + a.pad_t - tb0);
+    const int dt_lo = max(0, t + a.pad_t - (tb0 + tt_eff - 1));
+    const int nW = (dt_hi - dt_lo + 1) * 4 * C::BN;
+    char* wb = wbase + (s & 1) * C::W_BYTES;
+    const char* wsrc = a.wp + ((long long)((cc * TAPS + tap) * a.kt + dt_lo) * 4 * a.c_out + n0) * 16;
+    for (int sl = tid; sl < nW; sl += C::NTHREADS) {
+      const int dj = sl / C::BN, n = sl - dj * C::BN;  // dj = dtl*4 + j
+      if (n0 + n < a.c_out) glds16(wsrc + ((long long)dj * a.c_out + n) * 16, wb + (sl - lane) * 16);
+    }
+    if (tap == 0) {
+      char* xb = xbase + ((s / TAPS) & 1) * C::X_BYTES;
+      const char* xsrc = xclip + ((long long)t * a.H * a.W * a.ld_x + cc * CK) * ES;
+#pragma unroll
+      for (int it = 0; it < (C::X_SLOTS + C::NTHREADS - 1) / C::NTHREADS; ++it) {
+        const int sl = it * C::NTHREADS + tid;
+        if (sl < C::X_SLOTS) {
+          const int col = sl % C::PW, rowj = sl / C::PW, row = rowj % C::HR, j = rowj / C::HR;
+          if (col < C::HC) {
+            const int h = h0 + row - C::HALO, w = w0 + col - C::HALO;
+            const bool ok = (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+            const char* src = ok ? xsrc + ((long long)(h * a.W + w) * a.ld_x + j * CE) * ES : a.zeros;
+            glds16(src, xb + (sl - lane) * 16);
+          }
+        }
+      }
+    }
+  };
+
+  // ---- stage compute ------------------------------------------------------------------------------
+  auto compute = [&](int ti, int tap, int s) {
+    const int t = t_lo + ti;
+    const int dt_hi = min(a.kt - 1, t + a.pad_t - tb0);
+    const int dt_lo = max(0, t + a.pad_t - (tb0 + tt_eff - 1));
+    const char* xb = xbase + ((s / TAPS) & 1) * C::X_BYTES;
+    const char* wb = wbase + (s & 1) * C::W_BYTES;
+    const int dh = (TAPS == 9) ? tap / 3 : 0, dw = (TAPS == 9) ? tap - 3 * dh : 0;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      u32x4 av[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = 2 * (ws * MT + i) + (r >> 4) + dh, col = (r & 15) + dw;
+        av[i] = lds_read16(xb + (((2 * st + hh) * C::HR + row) * C::PW + col) * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < TT; ++j) {
+        const int dt = t + a.pad_t - (tb0 + j);
+        if (dt >= dt_lo && dt <= dt_hi) {
+#pragma unroll
+          for (int q = 0; q < NT; ++q) {
+            const int nt = wn * NT + q;
+            if (n0 + nt * 32 < a.c_out) {
+              const u32x4 bv = lds_read16(wb + (((dt - dt_lo) * 4 + 2 * st + hh) * C::BN + nt * 32 + r) * 16);
+#pragma unroll
+              for (int i = 0; i < MT; ++i) Mma<DT>::run(acc[j][i][q], av[i], bv);
+            }
+          }
+        }
+      }
+    }
+  };
+
+  // ---- main loop: one barrier per stage, next stage's DMA in flight during compute ----------------
+  int c_ti = 0, c_cc = 0, c_tap = 0, n_ti = 0, n_cc = 0, n_tap = 0;
+  auto advance = [&](int& ti, int& cc, int& tap) {
+    if (++tap == TAPS) {
+      tap = 0;
+      if (++cc == ncc) { cc = 0; ++ti; }
+    }
+  };
+  if (S > 0) {
+    issue(n_ti, n_cc, n_tap, 0);
+    advance(n_ti, n_cc, n_tap);
+  }
+  for (int s = 0; s < S; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < S) {
+      issue(n_ti, n_cc, n_tap, s + 1);
+      advance(n_ti, n_cc, n_tap);
+    }
+    compute(c_ti, c_tap, s);
+    advance(c_ti, c_cc, c_tap);
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------------------
+  float s1[NT], s2[NT];
+#pragma unroll
+  for (int q = 0; q < NT; ++q) s1[q] = s2[q] = 0.f;
+  T* yclip = (T*)a.y + (long long)b * a.y_bs;
+#pragma unroll
+  for (int q = 0; q < NT; ++q) {
+    const int n = n0 + (wn * NT + q) * 32 + r;
+    const bool nok = n < a.c_out;
+    const float bias = (a.bias && nok) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int j = 0; j < TT; ++j) {
+      const int to = tb0 + j;
+      if (to < a.t_out) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * hh;
+            const int h = h0 + 2 * (ws * MT + i) + (row >> 4), w = w0 + (row & 15);
+            if (nok && h < a.H && w < a.W) {
+              T* dst = yclip + ((long long)(to * a.H + h) * a.W + w) * a.ld_y + n;
+              float v = acc[j][i][q][e] + bias;
+              if (a.accumulate) v += Elt<DT>::to_f32(*dst);
+              *dst = Elt<DT>::from_f32(v);
+              s1[q] += v;
+              s2[q] += v * v;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (a.stat_part) {
+    __syncthreads();  // staging buffers are dead: reuse as reduction scratch
+    float* red = (float*)smem;  // [NWAVES][NT][32][2]
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const float t1 = s1[q] + __shfl_xor(s1[q], 32), t2 = s2[q] + __shfl_xor(s2[q], 32);
+      if (lane < 32) {
+        red[((wv * NT + q) * 32 + lane) * 2 + 0] = t1;
+        red[((wv * NT + q) * 32 + lane) * 2 + 1] = t2;
+      }
+    }
+    __syncthreads();
+    if (tid < C::BN && n0 + tid < a.c_out) {
+      const int wn_ = tid / (NT * 32), q = (tid / 32) % NT, l = tid & 31;
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < WS; ++k) {
+        t1 += red[(((wn_ * WS + k) * NT + q) * 32 + l) * 2 + 0];
+        t2 += red[(((wn_ * WS + k) * NT + q) * 32 + l) * 2 + 1];
+      }
+      const long long prow = ((long long)(b * a.t_blocks + tb) * a.tiles_h + th) * a.tiles_w + tw;
+      a.stat_part[(prow * 2 + 0) * a.c_out + n0 + tid] = t1;
+      a.stat_part[(prow * 2 + 1) * a.c_out + n0 + tid] = t2;
+    }
+  }
+}
+
+// ---- host-side planning ----------------------------------------------------------------------------
+struct ConvPlan {
+  int family;  // 0 narrow (c_out <= 32), 1 mid (c_out == 64), 2 wide
+  int TT, NT, TH, BN;
+  int tiles_w, tiles_h, t_blocks, n_blocks, t_out;
+};
+
+static int pick_tt(int t_out, int max_tt, const int* opts, int nopts) {
+  const int nblk = ceil_div(t_out, max_tt);
+  const int need = ceil_div(t_out, nblk);
+  for (int i = 0; i < nopts; ++i)
+    if (opts[i] >= need) return opts[i];
+  return opts[nopts - 1];
+}
+
+static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
+  SFVOS_REQUIRE(d != nullptr, "conv: null desc");
+  SFVOS_REQUIRE(d->dtype == SFVOS_F32 || d->dtype == SFVOS_BF16, "conv: bad dtype %d", d->dtype);
+  SFVOS_REQUIRE(d->taps == 9 || d->taps == 1, "conv: taps must be 9 or 1, got %d", d->taps);
+  SFVOS_REQUIRE(d->c_in > 0 && d->c_in % 32 == 0 && d->c_out > 0 && d->c_out % 32 == 0,
+                "conv: channels must be positive multiples of 32 (c_in %d, c_out %d)", d->c_in, d->c_out);
+  SFVOS_REQUIRE(d->c_out <= 256, "conv: c_out %d > 256 unsupported", d->c_out);
+  SFVOS_REQUIRE(d->batch >= 1 && d->t_in >= 1 && d->h >= 1 && d->w >= 1 && d->kt >= 1, "conv: bad extent");
+  SFVOS_REQUIRE(d->pad_t >= 0 && d->pad_t < d->kt + 1, "conv: bad pad_t %d", d->pad_t);
+  SFVOS_REQUIRE(d->ld_x >= d->c_in && d->ld_y >= d->c_out, "conv: pitch smaller than channel count");
+  const int ce = d->dtype == SFVOS_BF16 ? 8 : 4;
+  SFVOS_REQUIRE(d->ld_x % ce == 0, "conv: ld_x %d must be a multiple of %d (16-byte chunks)", d->ld_x, ce);
+  p->t_out = d->t_in + 2 * d->pad_t - d->kt + 1;
+  SFVOS_REQUIRE(p->t_out >= 1, "conv: kernel longer than padded input (t_in %d, kt %d, pad_t %d)", d->t_in, d->kt,
+                d->pad_t);
+  if (d->c_out <= 32) {
+    static const int opts[] = {1, 2, 3, 4, 6, 8, 11};
+    p->family = 0; p->TT = pick_tt(p->t_out, 11, opts, 7); p->NT = 1; p->TH = 16; p->BN = 32;
+  } else if (d->c_out == 64) {
+    static const int opts[] = {1, 2, 3, 4, 6};
+    p->family = 1; p->TT = pick_tt(p->t_out, 6, opts, 5); p->NT = 1; p->TH = 16; p->BN = 64;
+  } else {
+    static const int opts[] = {1, 2, 3};
+    p->family = 2; p->TT = pick_tt(p->t_out, 3, opts, 3); p->NT = d->c_out <= 192 ? 3 : 4; p->TH = 8;
+    p->BN = 64 * p->NT;
+  }
+  p->tiles_w = ceil_div(d->w, 16);
+  p->tiles_h = ceil_div(d->h, p->TH);
+  p->t_blocks = ceil_div(p->t_out, p->TT);
+  p->n_blocks = ceil_div(d->c_out, p->BN);
+  return SFVOS_OK;
+}
+
+template <int DT, int TAPS, int TT, int MT, int NT, int WS, int WN>
+static int launch(const ConvArgs& a, long long grid, hipStream_t stream) {
+  typedef ConvCfg<DT, TAPS, TT, MT, NT, WS, WN> C;
+  auto kern = conv3d_kernel<DT, TAPS, TT, MT, NT, WS, WN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("conv: hipFuncSetAttribute(%d B LDS) failed: %s", C::LDS_BYTES, hipGetErrorString(e));
+      return SFVOS_E_LAUNCH;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NTHREADS), C::LDS_BYTES, stream, a);
+  return check_launch("conv3d");
+}
+
+template <int DT, int TAPS>
+static int dispatch(const ConvPlan& p, const ConvArgs& a, long long grid, hipStream_t s) {
+#define SFVOS_CASE(F, TTv, MTv, NTv, WSv, WNv) \
+  if (p.family == F && p.TT == TTv && p.NT == NTv) return launch<DT, TAPS, TTv, MTv, NTv, WSv, WNv>(a, grid, s);
+  // narrow: 16x16 pixels x TT frames x 32 channels; each wave one 32-pixel M-tile, all frames
+  SFVOS_CASE(0, 1, 1, 1, 8, 1) SFVOS_CASE(0, 2, 1, 1, 8, 1) SFVOS_CASE(0, 3, 1, 1, 8, 1) SFVOS_CASE(0, 4, 1, 1, 8, 1)
+  SFVOS_CASE(0, 6, 1, 1, 8, 1) SFVOS_CASE(0, 8, 1, 1, 8, 1) SFVOS_CASE(0, 11, 1, 1, 8, 1)
+  if constexpr (TAPS == 1) {
+    // mid (lateral 32->64): 16x16 pixels x TT frames x 64 channels
+    SFVOS_CASE(1, 1, 2, 1, 4, 2) SFVOS_CASE(1, 2, 2, 1, 4, 2) SFVOS_CASE(1, 3, 2, 1, 4, 2) SFVOS_CASE(1, 4, 2, 1, 4, 2)
+    SFVOS_CASE(1, 6, 2, 1, 4, 2)
+  } else {
+    // wide: 8x16 pixels x TT frames x 192/256 channels
+    SFVOS_CASE(2, 1, 1, 3, 4, 2) SFVOS_CASE(2, 2, 1, 3, 4, 2) SFVOS_CASE(2, 3, 1, 3, 4, 2)
+    SFVOS_CASE(2, 1, 1, 4, 4, 2) SFVOS_CASE(2, 2, 1, 4, 4, 2) SFVOS_CASE(2, 3, 1, 4, 4, 2)
+  }
+#undef SFVOS_CASE
+  set_error("conv: no kernel instance for family %d TT %d NT %d taps %d", p.family, p.TT, p.NT, TAPS);
+  return SFVOS_E_ARG;
+}
+
+}  // namespace sfvos
+
+using namespace sfvos;
+
+extern "C" int sfvos_conv3d_stat_rows(const sfvos_conv_desc* d) {
+  ConvPlan p;
+  if (make_plan(d, &p) != SFVOS_OK) return SFVOS_E_ARG;
+  return d->batch * p.t_blocks * p.tiles_h * p.tiles_w;
+}
+
+extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
+                            float* stat_part, const void* zeros, sfvos_stream_t stream) {
+  ConvPlan p;
+  int rc = make_plan(d, &p);
+  if (rc != SFVOS_OK) return rc;
+  SFVOS_REQUIRE(x && w_packed && y && zeros, "conv: null pointer");
+  SFVOS_REQUIRE(!(d->taps == 9 && p.family == 1), "conv: 3x3 conv with c_out == 64 has no kernel instance");
+  SFVOS_REQUIRE(!(d->taps == 1 && p.family == 2), "conv: 1x1 conv with c_out > 64 has no kernel instance");
+  ConvArgs a;
+  a.x = (const char*)x; a.wp = (const char*)w_packed; a.bias = bias; a.y = (char*)y; a.stat_part = stat_part;
+  a.zeros = (const char*)zeros;
+  a.t_in = d->t_in; a.t_out = p.t_out; a.H = d->h; a.W = d->w; a.c_in = d->c_in; a.c_out = d->c_out; a.kt = d->kt;
+  a.pad_t = d->pad_t; a.ld_x = d->ld_x; a.ld_y = d->ld_y; a.accumulate = d->accumulate;
+  a.tiles_w = p.tiles_w; a.tiles_h = p.tiles_h; a.t_blocks = p.t_blocks; a.n_blocks = p.n_blocks;
+  a.x_bs = d->x_batch_stride; a.y_bs = d->y_batch_stride;
+  const long long grid = (long long)d->batch * p.t_blocks * p.n_blocks * p.tiles_h * p.tiles_w;
+  SFVOS_REQUIRE(grid > 0 && grid < (1ll << 31), "conv: grid %lld out of range", grid);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dtype == SFVOS_BF16)
+    return d->taps == 9 ? dispatch<SFVOS_BF16, 9>(p, a, grid, s) : dispatch<SFVOS_BF16, 1>(p, a, grid, s);
+  return d->taps == 9 ? dispatch<SFVOS_F32, 9>(p, a, grid, s) : dispatch<SFVOS_F32, 1>(p, a, grid, s);
+}

@@ -1,0 +1,50 @@
+// runtime.hip -- error convention and device check of the C ABI (include/sfvos.h).
+#include <string.h>
+
+#include "common.h"
+
+namespace sfvos {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return SFVOS_E_LAUNCH;
+  }
+  return SFVOS_OK;
+}
+
+}  // namespace sfvos
+
+extern "C" int sfvos_version(void) { return 100; }
+
+extern "C" const char* sfvos_last_error(void) { return sfvos::g_err; }
+
+extern "C" int sfvos_check_device(void) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) {
+    sfvos::set_error("no HIP device: %s", hipGetErrorString(e));
+    return SFVOS_E_NODEV;
+  }
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) {
+    sfvos::set_error("hipGetDeviceProperties failed: %s", hipGetErrorString(e));
+    return SFVOS_E_NODEV;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    sfvos::set_error("device %d is %s; libsfvos is built for gfx950 only", dev, prop.gcnArchName);
+    return SFVOS_E_NODEV;
+  }
+  return SFVOS_OK;
+}

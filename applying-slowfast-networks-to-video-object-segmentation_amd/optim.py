@@ -1,0 +1,69 @@
+"""FusedSGD -- torch.optim.SGD semantics as the reference configures it (train.py:80:
+lr 1e-3, momentum 0.9, weight_decay 1e-4, dampening 0, no nesterov), stepped on ONE flat fp32
+buffer by one libsfvos kernel (sfvos_sgd_step).
+
+The parameters stay ordinary nn.Parameters (the reference's `SGD(model.parameters())`
+keeps working on them); FusedSGD re-homes their storage into a flat buffer so that
+  * the optimiser step is a single launch, and
+  * the data-parallel gradient all-reduce is a single RCCL collective on the flat grad."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class FusedSGD(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, momentum=0.9, weight_decay=1e-4):
+        params = [p for p in params if p.requires_grad]
+        if not params:
+            raise ValueError('FusedSGD got no trainable parameters')
+        super(FusedSGD, self).__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        self._params = params
+        dev = params[0].device
+        if any(p.device != dev or p.dtype != torch.float32 for p in params):
+            raise ValueError('FusedSGD needs all parameters fp32 on one device')
+        n = sum(p.numel() for p in params)
+        self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_buf = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                self.flat_param[off:off + k].copy_(p.reshape(-1))
+                p.data = self.flat_param[off:off + k].view_as(p)
+                p.grad = self.flat_grad[off:off + k].view_as(p)
+                off += k
+        self._steps = 0
+
+    def zero_grad(self, set_to_none=False):
+        # grads are views of flat_grad: zero in place, never detach them
+        self.flat_grad.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise RuntimeError('FusedSGD does not take a closure')
+        g = self.param_groups[0]
+        if not self.flat_param.is_cuda:
+            raise RuntimeError('FusedSGD runs only on the GPU through libsfvos.so (no CPU fallback)')
+        for p in self._params:  # a caller may have replaced .grad (e.g. set_to_none); fold it back
+            if p.grad is None:
+                continue
+            if p.grad.data_ptr() < self.flat_grad.data_ptr() or \
+                    p.grad.data_ptr() >= self.flat_grad.data_ptr() + self.flat_grad.numel() * 4:
+                raise RuntimeError('FusedSGD: a parameter .grad was re-allocated outside the flat gradient buffer; '
+                                   'use optimizer.zero_grad() (set_to_none=False)')
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.call('sfvos_sgd_step', _ptr(self.flat_param), _ptr(self.flat_grad), _ptr(self.flat_buf),
+                  self.flat_param.numel(), float(g['lr']), float(g['momentum']), float(g['weight_decay']),
+                  1 if self._steps == 0 else 0, st)
+        self._steps += 1
+        # the kernel wrote the parameters through raw pointers: autograd's version counters did not
+        # move, so invalidate the packed-weight caches explicitly
+        _lib.bump_weight_epoch()

@@ -1,0 +1,160 @@
+"""bench.py -- clips/s of the SlowFastLayers hot path (fwd + bwd + SGD) on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+torch.distributed.run with one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
+
+Workload = BASELINE.json configs[1] restated in the reference's own parametrisation:
+(slow, fast) = (4, 32) frames, one clip = one call of temporally_enhance_features over the five FPN
+levels of a 480x854 DAVIS frame (P = 85 932 positions), bf16 activations / f32 accumulate, inputs
+resident in HBM as channels-last clips, synthetic N(0,1) features, random-init weights.
+A step = forward + backward of one clip; gradients are accumulated over 2 clips and then the
+optimiser steps (reference model.py:369-374), with the data-parallel all-reduce in front of it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=4)
+    ap.add_argument('--sp', type=int, default=4)
+    ap.add_argument('--fp', type=int, default=32)
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-threads', type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(sp, fp, threads):
+    """The oracle (torch-CPU restatement of the reference path) timed on this box's host cores on a
+    bounded sample: ONE clip's FPN level '1' (96x168 = 18.8 % of the clip's positions), fwd+bwd."""
+    from oracle.slowfast_ref import OracleSlowFastLayers, proxy_loss
+    from sfvos_amd import davis_pyramid
+    if threads > 0:
+        torch.set_num_threads(threads)
+    cores = torch.get_num_threads()
+    pyr = dict(davis_pyramid())
+    H, W = pyr['1']
+    P = sum(h * w for h, w in pyr.values())
+    torch.manual_seed(63)
+    m = OracleSlowFastLayers(256, torch.device('cpu'), sp, fp)
+    m.train()
+    fast = torch.randn(1, 256, fp, H, W)
+    slow = fast[:, :, fp // 2 - sp // 2: fp // 2 + (sp + 1) // 2]
+    t0 = time.time()
+    s, f = m(slow, fast)
+    loss = proxy_loss({'1': torch.cat([s, f], 1).squeeze(2)})
+    loss.backward()
+    dt = time.time() - t0
+    frac = float(H * W) / P
+    return {'value': frac / dt, 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
+            'sample': "oracle fwd+bwd of FPN level '1' (96x168, %.1f%% of one clip's positions) in %.1f s, "
+                      "scaled by position share" % (100 * frac, dt)}
+
+
+def main():
+    args = parse()
+    from sfvos_amd import FusedSGD, GradBucket, SlowFastLayers, davis_pyramid, init_distributed
+    from oracle.slowfast_ref import proxy_loss  # loss definition only (SURVEY.md 8d stand-in for RoI-head losses)
+
+    rank, world, local = init_distributed()
+    if world != args.gpus:
+        if rank == 0 and world > 1:
+            print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+    dev = torch.device('cuda', local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    torch.manual_seed(63)
+    model = SlowFastLayers(256, dev, args.sp, args.fp, precision=args.precision).to(dev)
+    model.train()
+    opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    bucket = GradBucket(opt.flat_grad)
+    tdt = torch.bfloat16 if args.precision == 'bf16' else torch.float32
+    pyr = davis_pyramid()
+    P = sum(h * w for _, (h, w) in pyr)
+    gen = torch.Generator(device=dev).manual_seed(63 + rank)
+    fast, slow = {}, {}
+    for key, (h, w) in pyr:
+        fast[key] = torch.randn((1, args.fp, h, w, 256), generator=gen, device=dev, dtype=torch.float32).to(tdt)
+        lo = args.fp // 2 - args.sp // 2
+        slow[key] = fast[key][:, lo: lo + args.sp].contiguous()
+
+    timer = model.enable_kernel_timer()
+
+    def step(i):
+        out = model.temporally_enhance_features_ndhwc(slow, fast)
+        proxy_loss(out).backward()
+        if i % 2 == 1:  # model.py:372-374: optimiser every 2nd clip
+            bucket.all_reduce()
+            opt.step()
+            opt.zero_grad()
+
+    for i in range(args.warmup):
+        step(i)
+    timer.reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        plan = model.plan
+        kern = timer.summary()  # name -> (calls, mean ms)
+        # dominant kernel: fast_conv1 forward at FPN level '0' (72 % of the forward FLOPs)
+        h0, w0 = pyr[0][1]
+        l = plan.layer('f1')
+        dom_flops = 2.0 * l.c_in * l.c_out * l.kt * l.taps * l.t_out * h0 * w0
+        dom = kern.get('conv_fwd/f1/%dx%d' % (h0, w0))
+        peak = 2500.0 if args.precision == 'bf16' else 157.3
+        roofline = None
+        if dom:
+            ach = dom_flops / (dom[1] * 1e-3) / 1e12
+            roofline = {'bound': 'mfma', 'kernel': 'conv3d_kernel fast_conv1 fwd, level 0 (192x336)',
+                        'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                        'launch_ms': round(dom[1], 4), 'flops_per_launch': dom_flops, 'traffic': None}
+        total_flops = plan.train_flops(P)
+        line = {
+            'metric': 'clips/sec (T=32, 480x854) fwd+bwd', 'value': round(world * args.steps / dt, 4),
+            'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
+            'config': {'workload': 'SlowFastLayers (sp=%d, fp=%d) fwd+bwd+SGD, 1 clip/GPU/step, 5 FPN levels of a '
+                                   '480x854 frame (P=%d), NDHWC inputs resident in HBM' % (args.sp, args.fp, P),
+                       'parallelism': 'dp%d' % world, 'grad_accumulation': 2},
+            'tflops_per_clip': round(total_flops / 1e12, 3),
+            'achieved_tflops_whole_step': round(total_flops * world * args.steps / dt / 1e12, 2),
+            'roofline': roofline,
+            'kernels_ms': {k: [v[0], round(v[1], 4)] for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:24]},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line['cpu_baseline'] = cpu_baseline(args.sp, args.fp, args.cpu_threads)
+        else:
+            line['cpu_baseline'] = None
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

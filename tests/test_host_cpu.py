@@ -1,0 +1,117 @@
+"""CPU (no GPU): host-side logic of the build -- planner tables, module surface/state-dict,
+C-ABI symbol export -- and the loud failure when asked to compute without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from golden_util import load_tables
+from oracle.slowfast_ref import OracleSlowFastLayers
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_planner_kernel_sizes_match_reference_tables():
+    from sfvos_amd import SlowFastPlan, calc_kernel_sizes
+    t = load_tables()
+    for p, ks in t['calc_kernel_sizes'].items():
+        assert list(calc_kernel_sizes(int(p))) == ks
+    for key, ks in t['kernel_sizes'].items():
+        sp, fp = map(int, key.split('-'))
+        plan = SlowFastPlan(256, sp, fp)
+        assert list(plan.k_slow) == ks['slow'] and list(plan.k_fast) == ks['fast'] and list(plan.k_lat) == ks['lateral']
+        assert plan.param_count() == t['param_counts'][key]
+        # temporal extents collapse to exactly one frame
+        assert plan.layer('s3').t_out == 1 and plan.layer('f3').t_out == 1
+        assert plan.layer('l1').t_out == plan.layer('s1').t_out and plan.layer('l2').t_out == plan.layer('s2').t_out
+
+
+def test_planner_rejects_impossible_configs():
+    from sfvos_amd import SlowFastPlan
+    with pytest.raises(ValueError):
+        SlowFastPlan(256, 7, 1)      # lateral kernel would be < 1
+    with pytest.raises(ValueError):
+        SlowFastPlan(100, 1, 1)      # channels not a multiple of the MFMA tile
+    with pytest.raises(ValueError):
+        SlowFastPlan(256, 0, 3)
+
+
+def test_flop_model_matches_survey():
+    from sfvos_amd import SlowFastPlan, davis_pyramid
+    P = sum(h * w for _, (h, w) in davis_pyramid())
+    assert P == 85932
+    plan = SlowFastPlan(256, 4, 32)
+    assert abs(plan.forward_flops(P) / 1e9 - 4261) < 2
+    assert abs(plan.train_flops(P) / 1e9 - 9260) < 4             # row a9
+    assert abs(plan.train_flops(P, True) / 1e9 - 12783) < 6
+    assert abs(plan.layer_flops(P)['f1'] / 1e9 - 3066.4) < 1
+    assert abs(SlowFastPlan(256, 1, 1).forward_flops(P) / 1e9 - 257) < 1
+
+
+@pytest.mark.parametrize('sp,fp', [(1, 1), (3, 7), (4, 32)])
+def test_module_surface_matches_reference(sp, fp):
+    from sfvos_amd import SlowFastLayers
+    torch.manual_seed(63)
+    m = SlowFastLayers(256, torch.device('cpu'), sp, fp)
+    torch.manual_seed(63)
+    o = OracleSlowFastLayers(256, torch.device('cpu'), sp, fp)
+    sd, so = m.state_dict(), o.state_dict()
+    assert list(sd.keys()) == list(so.keys())
+    for k in sd:
+        assert sd[k].shape == so[k].shape and sd[k].dtype == so[k].dtype
+        assert torch.equal(sd[k], so[k]), 'default init differs for %s (RNG order)' % k
+    assert [n for n, _ in m.named_parameters()] == [n for n, _ in o.named_parameters()]
+    if (sp, fp) == (3, 7):
+        t = load_tables()['state_dict']
+        assert list(sd.keys()) == list(t.keys())
+    m.load_state_dict(so, strict=True)
+    assert m.training and not m.eval().training
+
+
+def test_no_cpu_fallback():
+    from sfvos_amd import FusedSGD, SlowFastLayers
+    m = SlowFastLayers(256, torch.device('cpu'), 1, 1)
+    x = torch.zeros(1, 256, 1, 4, 4)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m(x, x)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m.temporally_enhance_features([{'0': x[0].transpose(0, 1)}], [{'0': x[0].transpose(0, 1)}])
+    opt = FusedSGD(m.parameters())
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        opt.step()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'applying-slowfast-networks-to-video-object-segmentation_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), f
+                assert 'conv3d(' not in src.replace('sfvos_conv3d(', '').replace('_conv3d(', '') or f.endswith('.hip'), f
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    from sfvos_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'sfvos.h')).read()
+    declared = set(re.findall(r'\b(sfvos_[a-z0-9_]+)\s*\(', header))
+    declared -= {'sfvos_conv_desc'}
+    assert declared == set(_lib.SIGNATURES.keys()), declared ^ set(_lib.SIGNATURES.keys())
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('libsfvos.so not built (run `python __graft_entry__.py`)')
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.sfvos_version.restype = ctypes.c_int
+    assert lib.sfvos_version() >= 100
+    # struct mirror: size must match the C struct (13 ints + padding + 2 int64 = 72 bytes)
+    assert ctypes.sizeof(_lib.ConvDesc) == 72
+
+
+def test_shard_clips():
+    from sfvos_amd.parallel import shard_clips
+    assert shard_clips(10, 0, 4) == [0, 4, 8] and shard_clips(10, 3, 4) == [3, 7]
+    got = sorted(i for r in range(8) for i in shard_clips(37, r, 8))
+    assert got == list(range(37))
