@@ -9,13 +9,20 @@ namespace sfvos {
 template <int DT> __device__ __forceinline__ void unpack(const u32x4& v, float* f);
 template <> __device__ __forceinline__ void unpack<SFVOS_F32>(const u32x4& v, float* f) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) f[e] = __builtin_bit_cast(float, v[e]);
+  for (int e = 0; e < 4; ++e) {
+    // copy the lane to a scalar first: hipcc (ROCm 7.2) mis-compiles __builtin_bit_cast applied
+    // directly to an ext-vector element lvalue (every e reads element 0)
+    const unsigned u = v[e];
+    f[e] = __builtin_bit_cast(float, u);
+  }
 }
 template <> __device__ __forceinline__ void unpack<SFVOS_BF16>(const u32x4& v, float* f) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    f[2 * e] = __builtin_bit_cast(float, v[e] << 16);
-    f[2 * e + 1] = __builtin_bit_cast(float, v[e] & 0xffff0000u);
+    const unsigned u = v[e];
+    const unsigned lo = u << 16, hi = u & 0xffff0000u;
+    f[2 * e] = __builtin_bit_cast(float, lo);
+    f[2 * e + 1] = __builtin_bit_cast(float, hi);
   }
 }
 template <int DT> __device__ __forceinline__ u32x4 pack(const float* f);

@@ -360,7 +360,10 @@ class SlowFastLayers(nn.Module):
         self._check_ready(fast)
         names = [n for n, _ in self.named_parameters()]
         params = [p for _, p in self.named_parameters()]
-        return _SlowFastLevelFn.apply(self, ndhwc_input, names, slow, fast, *params)
+        # decided here: inside Function.forward grad mode is always off
+        keep = torch.is_grad_enabled() and (slow.requires_grad or fast.requires_grad
+                                            or any(p.requires_grad for p in params))
+        return _SlowFastLevelFn.apply(self, (ndhwc_input, keep), names, slow, fast, *params)
 
     def forward(self, slow, fast):
         """(slow [B,C,Ts,H,W], fast [B,C,Tf,H,W]) -> (slow [B,224,1,H,W], fast [B,32,1,H,W]) -- model.py:118-149."""
@@ -390,9 +393,8 @@ class SlowFastLayers(nn.Module):
 
 class _SlowFastLevelFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module, ndhwc_input, names, slow, fast, *params):
-        keep = torch.is_grad_enabled() and (slow.requires_grad or fast.requires_grad
-                                            or any(p.requires_grad for p in params))
+    def forward(ctx, module, flags, names, slow, fast, *params):
+        ndhwc_input, keep = flags
         merged, state = module._engine_forward(slow.detach(), fast.detach(), ndhwc_input, keep)
         ctx.module, ctx.state, ctx.names, ctx.ndhwc_input = module, state, names, ndhwc_input
         ctx.in_meta = (slow.shape, slow.dtype, fast.shape, fast.dtype)

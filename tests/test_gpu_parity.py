@@ -200,8 +200,8 @@ def test_full_size_properties_headline_config():
         assert torch.equal(a, b), 'two runs differ: the path must be deterministic'
         mean = a.double().mean((0, 2, 3)).cpu()
         var = a.double().var((0, 2, 3), unbiased=False).cpu()
-        beta = torch.cat([m.bn_s3.bias, m.bn_f3.bias]).double().cpu()
-        gamma = torch.cat([m.bn_s3.weight, m.bn_f3.weight]).double().cpu()
+        beta = torch.cat([m.bn_s3.bias, m.bn_f3.bias]).detach().double().cpu()
+        gamma = torch.cat([m.bn_s3.weight, m.bn_f3.weight]).detach().double().cpu()
         assert float((mean - beta).abs().max()) < 2e-2
         assert float((var.sqrt() - gamma.abs()).abs().max()) < 2e-2
         m32, _ = build(4, 32, 'fp32')
