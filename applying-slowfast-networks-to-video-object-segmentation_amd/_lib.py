@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libsfvos.so')
+LIB_PATH = os.environ.get('SFVOS_LIB') or os.path.join(_HERE, 'csrc', 'libsfvos.so')  # SFVOS_LIB: A/B builds
 
 F32, BF16 = 0, 1
 

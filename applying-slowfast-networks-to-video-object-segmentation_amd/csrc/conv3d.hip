@@ -4,17 +4,23 @@
 // pad_t = kt-1 the same kernel is aten::convolution_backward's grad_input.
 //
 // Decomposition (one workgroup = 8 waves, 2 per SIMD):
-//   output tile  = TT output frames x (TH x 16) pixels x BN output channels
-//   K loop       = stages (input frame t, 64-byte channel chunk cc, spatial tap)
-//   per stage    : the (TH+2)x18 halo tile of frame t / chunk cc sits in LDS (re-used by the 9
-//                  taps and by every output frame t feeds: dt = t - t_out), and the weight
-//                  slice W[dt_lo..dt_hi][tap][cc][BN] is streamed next to it.
-//   staging      : global_load_lds (LDS-DMA) 16 B per lane, double-buffered, one barrier per stage.
-//   LDS images   : chunk-major [16B chunk j][row][col] / [dt][j][n] so every ds_read_b128 of an
-//                  MFMA operand touches 16 consecutive 16-B slots per lane group: conflict-free.
-//   MFMA         : A = 32 pixels (2 rows x 16) x 16B-chunk pair, B = weights; f32 accumulate.
+//   output tile  = TT output frames x (TH rows x 32 px) x BN output channels, f32 accumulators
+//   K loop       = for 64-byte channel chunk cc / for temporal tap dt / for tap group tg
+//   temporal ring: the halo tiles ((TH+2) x 34 px x 64 B) of TT+1 consecutive input frames sit in
+//                  LDS.  At temporal tap dt output frame j reads ring frame dt+j, so one weight
+//                  slice W[dt][taps][cc] feeds all TT frames (weights are streamed ONCE per
+//                  workgroup) and every ring frame is re-used by 9 spatial taps x up to TT
+//                  temporal taps.  While tap dt computes, frame dt+TT is DMA'd into the free slot.
+//   staging      : global_load_lds (LDS-DMA) 16 B per lane; weights double-buffered; one barrier
+//                  per stage.  Out-of-image / out-of-clip pixels come from a zero page.
+//   LDS images   : chunk-major [16B chunk][row][col] and [tap][chunk][n]: every ds_read_b128 of an
+//                  MFMA operand covers 32 consecutive 16-B slots per half-wave -> conflict-free.
+//   inner loop   : branch-free: per (tap, k-step) NT B-fragment + TT*MT A-fragment reads feed
+//                  TT*MT*NT MFMAs (32x32x16 bf16, or 4 x 32x32x2 exact f32).
 //   epilogue     : + bias, optional += y, store as dtype, per-channel (sum, sumsq) of the tile
 //                  written as one deterministic partial row per workgroup (BN statistics).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace sfvos {
@@ -29,31 +35,35 @@ struct ConvArgs {
   int t_in, t_out, H, W, c_in, c_out, kt, pad_t, ld_x, ld_y, accumulate;
   int tiles_w, tiles_h, t_blocks, n_blocks;
   long long x_bs, y_bs;
+  int debug;  // timing-only: bit0 skip compute, bit1 skip DMA after the first stage (results wrong)
 };
 
-template <int DT, int TAPS, int TT, int MT, int NT, int WS, int WN>
+template <int DT, int TAPS, int TPS, int TT, int MT, int NT, int WS, int WN>
 struct ConvCfg {
   static constexpr int NWAVES = WS * WN, NTHREADS = 64 * NWAVES;
-  static constexpr int TH = 2 * WS * MT, TW = 16;
+  static constexpr int TH = WS * MT, TW = 32;
   static constexpr int HALO = (TAPS == 9) ? 1 : 0;
-  static constexpr int HR = TH + 2 * HALO;
-  static constexpr int HC = TW + 2 * HALO;
-  static constexpr int PW = (TAPS == 9) ? 32 : 16;  // row pitch in 16-B slots, multiple of 16
+  static constexpr int HR = TH + 2 * HALO, HC = TW + 2 * HALO;
   static constexpr int BN = WN * NT * 32;
-  static constexpr int X_SLOTS = 4 * HR * PW;
-  static constexpr int X_BYTES = X_SLOTS * 16;
-  static constexpr int W_BYTES = TT * 4 * BN * 16;
-  static constexpr int LDS_BYTES = 2 * X_BYTES + 2 * W_BYTES;
+  static constexpr int R = TT + 1;                    // ring slots
+  static constexpr int X_SLOTS = 4 * HR * HC;         // 16-B slots per ring frame
+  static constexpr int X_BYTES = ((X_SLOTS * 16 + 255) / 256) * 256;
+  static constexpr int W_SLOTS = TPS * 4 * BN;
+  static constexpr int W_BYTES = W_SLOTS * 16;
+  static constexpr int NTG = TAPS / TPS;
+  static constexpr int LDS_BYTES = R * X_BYTES + 2 * W_BYTES;
+  static_assert(TAPS % TPS == 0, "tap groups must tile the taps");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <int DT, int TAPS, int TT, int MT, int NT, int WS, int WN>
+template <int DT, int TAPS, int TPS, int TT, int MT, int NT, int WS, int WN>
 __global__ __launch_bounds__(64 * WS * WN) void conv3d_kernel(ConvArgs a) {
-  typedef ConvCfg<DT, TAPS, TT, MT, NT, WS, WN> C;
+  typedef ConvCfg<DT, TAPS, TPS, TT, MT, NT, WS, WN> C;
   typedef typename Elt<DT>::type T;
   constexpr int CE = Elt<DT>::CE, CK = 4 * CE, ES = 16 / CE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const xbase = smem;
-  char* const wbase = smem + 2 * C::X_BYTES;
+  char* const ring = smem;
+  char* const wbase = smem + C::R * C::X_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,14 +77,10 @@ __global__ __launch_bounds__(64 * WS * WN) void conv3d_kernel(ConvArgs a) {
   const int tb = bid % a.t_blocks; bid /= a.t_blocks;
   const int b = bid;
   const int h0 = th * C::TH, w0 = tw * C::TW, n0 = nb * C::BN, tb0 = tb * TT;
-  const int tt_eff = min(TT, a.t_out - tb0);
 
-  const int t_lo = max(0, tb0 - a.pad_t);
-  const int t_hi = min(a.t_in - 1, tb0 + tt_eff - 1 - a.pad_t + a.kt - 1);
-  const int n_tin = max(0, t_hi - t_lo + 1);
+  const int NF = TT + a.kt - 1;  // input frames this workgroup touches: t = tb0 - pad_t + i
   const int ncc = a.c_in / CK;
-  const int S = n_tin * ncc * TAPS;
-
+  const int S = ncc * a.kt * C::NTG;
   const char* xclip = a.x + (long long)b * a.x_bs * ES;
 
   f32x16 acc[TT][MT][NT];
@@ -87,95 +93,107 @@ __global__ __launch_bounds__(64 * WS * WN) void conv3d_kernel(ConvArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][i][q][e] = 0.f;
 
-  // ---- stage issue: LDS-DMA of the weight slice (+ halo tile when tap == 0) -------------------
-  auto issue = [&](int ti, int cc, int tap, int s) {
-    const int t = t_lo + ti;
-    const int dt_hi = min(a.kt - 1, t + a.pad_t - tb0);
-    const int dt_lo = max(0, t + a.pad_t - (tb0 + tt_eff - 1));
-    const int nW = (dt_hi - dt_lo + 1) * 4 * C::BN;
+  // ---- DMA: one ring frame (halo tile of input frame i, channel chunk cc) ----------------------
+  auto issue_frame = [&](int cc, int i) {
+    const int t = tb0 - a.pad_t + i;
+    const bool t_ok = (unsigned)t < (unsigned)a.t_in;
+    char* xb = ring + ((cc * NF + i) % C::R) * C::X_BYTES;
+    const char* xsrc = xclip + ((long long)t * a.H * a.W * a.ld_x + cc * CK) * ES;
+#pragma unroll
+    for (int it = 0; it < (C::X_SLOTS + C::NTHREADS - 1) / C::NTHREADS; ++it) {
+      const int sl = it * C::NTHREADS + tid;
+      if (sl < C::X_SLOTS) {
+        const int col = sl % C::HC, rowj = sl / C::HC, row = rowj % C::HR, j = rowj / C::HR;
+        const int h = h0 + row - C::HALO, w = w0 + col - C::HALO;
+        const bool ok = t_ok && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+        const char* src = ok ? xsrc + ((long long)(h * a.W + w) * a.ld_x + j * CE) * ES : a.zeros;
+        glds16(src, xb + (sl - lane) * 16);
+      }
+    }
+  };
+  // ---- DMA: weight slice of stage s = (cc, dt, tg): [TPS taps][4 chunks][BN] -------------------
+  auto issue_w = [&](int cc, int dt, int tg, int s) {
     char* wb = wbase + (s & 1) * C::W_BYTES;
-    const char* wsrc = a.wp + ((long long)((cc * TAPS + tap) * a.kt + dt_lo) * 4 * a.c_out + n0) * 16;
-    for (int sl = tid; sl < nW; sl += C::NTHREADS) {
-      const int dj = sl / C::BN, n = sl - dj * C::BN;  // dj = dtl*4 + j
-      if (n0 + n < a.c_out) glds16(wsrc + ((long long)dj * a.c_out + n) * 16, wb + (sl - lane) * 16);
-    }
-    if (tap == 0) {
-      char* xb = xbase + ((s / TAPS) & 1) * C::X_BYTES;
-      const char* xsrc = xclip + ((long long)t * a.H * a.W * a.ld_x + cc * CK) * ES;
+    const char* wsrc = a.wp + (((long long)(cc * a.kt + dt) * TAPS + tg * TPS) * 4 * a.c_out + n0) * 16;
 #pragma unroll
-      for (int it = 0; it < (C::X_SLOTS + C::NTHREADS - 1) / C::NTHREADS; ++it) {
-        const int sl = it * C::NTHREADS + tid;
-        if (sl < C::X_SLOTS) {
-          const int col = sl % C::PW, rowj = sl / C::PW, row = rowj % C::HR, j = rowj / C::HR;
-          if (col < C::HC) {
-            const int h = h0 + row - C::HALO, w = w0 + col - C::HALO;
-            const bool ok = (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
-            const char* src = ok ? xsrc + ((long long)(h * a.W + w) * a.ld_x + j * CE) * ES : a.zeros;
-            glds16(src, xb + (sl - lane) * 16);
-          }
-        }
+    for (int it = 0; it < (C::W_SLOTS + C::NTHREADS - 1) / C::NTHREADS; ++it) {
+      const int sl = it * C::NTHREADS + tid;
+      if (sl < C::W_SLOTS) {
+        const int tj = sl / C::BN, n = sl - tj * C::BN;  // tj = tap_local*4 + chunk
+        if (n0 + n < a.c_out) glds16(wsrc + ((long long)tj * a.c_out + n) * 16, wb + (sl - lane) * 16);
       }
     }
   };
 
-  // ---- stage compute ------------------------------------------------------------------------------
-  auto compute = [&](int ti, int tap, int s) {
-    const int t = t_lo + ti;
-    const int dt_hi = min(a.kt - 1, t + a.pad_t - tb0);
-    const int dt_lo = max(0, t + a.pad_t - (tb0 + tt_eff - 1));
-    const char* xb = xbase + ((s / TAPS) & 1) * C::X_BYTES;
+  // ---- one stage of MFMAs --------------------------------------------------------------------------
+  auto compute = [&](int cc, int dt, int tg, int s) {
     const char* wb = wbase + (s & 1) * C::W_BYTES;
-    const int dh = (TAPS == 9) ? tap / 3 : 0, dw = (TAPS == 9) ? tap - 3 * dh : 0;
+    const char* xf[TT];
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      u32x4 av[MT];
+    for (int j = 0; j < TT; ++j) xf[j] = ring + ((cc * NF + dt + j) % C::R) * C::X_BYTES;
+    // k-step k = (tap_local, st): operand fragments of step k+1 are read from LDS while the MFMAs
+    // of step k run (software pipeline in registers; the waits become counted, not lgkmcnt(0)).
+    u32x4 bv[2][NT], av[2][TT][MT];
+    auto load = [&](int k, int buf) {
+#ifdef SFVOS_ABLATE  // timing-only builds (scratch): 1 = no A re-reads, 2 = no B re-reads, 3 = neither
+      const bool skip_a = (SFVOS_ABLATE & 1) && k > 1, skip_b = (SFVOS_ABLATE & 2) && k > 1;
+#else
+      constexpr bool skip_a = false, skip_b = false;
+#endif
+      const int tp = k >> 1, st = k & 1;
+      const int tap = tg * TPS + tp;
+      const int dh = (TAPS == 9) ? tap / 3 : 0, dw = (TAPS == 9) ? tap - 3 * dh : 0;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int row = 2 * (ws * MT + i) + (r >> 4) + dh, col = (r & 15) + dw;
-        av[i] = lds_read16(xb + (((2 * st + hh) * C::HR + row) * C::PW + col) * 16);
-      }
+      for (int q = 0; q < NT; ++q)
+        if (!skip_b) bv[buf][q] = lds_read16(wb + (((tp * 4 + 2 * st + hh) * C::BN) + (wn * NT + q) * 32 + r) * 16);
 #pragma unroll
-      for (int j = 0; j < TT; ++j) {
-        const int dt = t + a.pad_t - (tb0 + j);
-        if (dt >= dt_lo && dt <= dt_hi) {
+      for (int j = 0; j < TT; ++j)
 #pragma unroll
-          for (int q = 0; q < NT; ++q) {
-            const int nt = wn * NT + q;
-            if (n0 + nt * 32 < a.c_out) {
-              const u32x4 bv = lds_read16(wb + (((dt - dt_lo) * 4 + 2 * st + hh) * C::BN + nt * 32 + r) * 16);
+        for (int i = 0; i < MT; ++i)
+          if (!skip_a) av[buf][j][i] = lds_read16(xf[j] + (((2 * st + hh) * C::HR + ws * MT + i + dh) * C::HC + r + dw) * 16);
+    };
+    load(0, 0);
 #pragma unroll
-              for (int i = 0; i < MT; ++i) Mma<DT>::run(acc[j][i][q], av[i], bv);
-            }
+    for (int k = 0; k < 2 * TPS; ++k) {
+      if (k + 1 < 2 * TPS) load(k + 1, (k + 1) & 1);
+      // pin the order: hipcc otherwise sinks each ds_read next to its MFMA and drains lgkmcnt(0)
+      // before every MFMA (LDS-latency-bound stream)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < TT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int q = 0; q < NT; ++q) Mma<DT>::run(acc[j][i][q], av[k & 1][j][i], bv[k & 1][q]);
+    }
+  };
+
+  // ---- main loop -------------------------------------------------------------------------------------
+  int s = 0;
+  for (int cc = 0; cc < ncc; ++cc) {
+    // chunk prologue: refill the ring with frames 0..TT-1 of this chunk.  All waves must have
+    // finished the previous chunk's last stage before its live slots are overwritten.
+    if (cc > 0) __syncthreads();
+    for (int i = 0; i < TT; ++i) issue_frame(cc, i);
+    if (cc == 0) issue_w(0, 0, 0, 0);
+    for (int dt = 0; dt < a.kt; ++dt) {
+      for (int tg = 0; tg < C::NTG; ++tg, ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // stage s operands landed; everyone is done with stage s-1
+        if (!(a.debug & 2)) {
+          if (tg == 0 && dt + TT < NF) issue_frame(cc, dt + TT);  // slot freed by frame dt-1
+          if (s + 1 < S) {
+            int ntg = tg + 1, ndt = dt, ncc2 = cc;
+            if (ntg == C::NTG) { ntg = 0; if (++ndt == a.kt) { ndt = 0; ++ncc2; } }
+            issue_w(ncc2, ndt, ntg, s + 1);
           }
         }
+        if (!(a.debug & 1)) compute(cc, dt, tg, s);
       }
     }
-  };
-
-  // ---- main loop: one barrier per stage, next stage's DMA in flight during compute ----------------
-  int c_ti = 0, c_cc = 0, c_tap = 0, n_ti = 0, n_cc = 0, n_tap = 0;
-  auto advance = [&](int& ti, int& cc, int& tap) {
-    if (++tap == TAPS) {
-      tap = 0;
-      if (++cc == ncc) { cc = 0; ++ti; }
-    }
-  };
-  if (S > 0) {
-    issue(n_ti, n_cc, n_tap, 0);
-    advance(n_ti, n_cc, n_tap);
-  }
-  for (int s = 0; s < S; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (s + 1 < S) {
-      issue(n_ti, n_cc, n_tap, s + 1);
-      advance(n_ti, n_cc, n_tap);
-    }
-    compute(c_ti, c_tap, s);
-    advance(c_ti, c_cc, c_tap);
   }
 
-  // ---- epilogue -----------------------------------------------------------------------------------
+  // ---- epilogue --------------------------------------------------------------------------------------
   float s1[NT], s2[NT];
 #pragma unroll
   for (int q = 0; q < NT; ++q) s1[q] = s2[q] = 0.f;
@@ -191,10 +209,10 @@ __global__ __launch_bounds__(64 * WS * WN) void conv3d_kernel(ConvArgs a) {
       if (to < a.t_out) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
+          const int h = h0 + ws * MT + i;
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * hh;
-            const int h = h0 + 2 * (ws * MT + i) + (row >> 4), w = w0 + (row & 15);
+            const int w = w0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
             if (nok && h < a.H && w < a.W) {
               T* dst = yclip + ((long long)(to * a.H + h) * a.W + w) * a.ld_y + n;
               float v = acc[j][i][q][e] + bias;
@@ -237,17 +255,15 @@ __global__ __launch_bounds__(64 * WS * WN) void conv3d_kernel(ConvArgs a) {
 
 // ---- host-side planning ----------------------------------------------------------------------------
 struct ConvPlan {
-  int family;  // 0 narrow (c_out <= 32), 1 mid (c_out == 64), 2 wide
+  int family;  // 0 narrow (c_out <= 32), 1 mid (c_out == 64, 1x1), 2 wide
   int TT, NT, TH, BN;
   int tiles_w, tiles_h, t_blocks, n_blocks, t_out;
 };
 
-static int pick_tt(int t_out, int max_tt, const int* opts, int nopts) {
+static int pick_tt(int t_out, int max_tt) {
+  // fewest frame blocks first, then the smallest TT that covers them
   const int nblk = ceil_div(t_out, max_tt);
-  const int need = ceil_div(t_out, nblk);
-  for (int i = 0; i < nopts; ++i)
-    if (opts[i] >= need) return opts[i];
-  return opts[nopts - 1];
+  return ceil_div(t_out, nblk);
 }
 
 static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
@@ -266,27 +282,25 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
   SFVOS_REQUIRE(p->t_out >= 1, "conv: kernel longer than padded input (t_in %d, kt %d, pad_t %d)", d->t_in, d->kt,
                 d->pad_t);
   if (d->c_out <= 32) {
-    static const int opts[] = {1, 2, 3, 4, 6, 8, 11};
-    p->family = 0; p->TT = pick_tt(p->t_out, 11, opts, 7); p->NT = 1; p->TH = 16; p->BN = 32;
-  } else if (d->c_out == 64) {
-    static const int opts[] = {1, 2, 3, 4, 6};
-    p->family = 1; p->TT = pick_tt(p->t_out, 6, opts, 5); p->NT = 1; p->TH = 16; p->BN = 64;
+    p->family = 0; p->TT = pick_tt(p->t_out, 4); p->NT = 1; p->TH = 8; p->BN = 32;
+  } else if (d->c_out == 64 && d->taps == 1) {
+    p->family = 1; p->TT = pick_tt(p->t_out, 3); p->NT = 1; p->TH = 8; p->BN = 64;
   } else {
-    static const int opts[] = {1, 2, 3};
-    p->family = 2; p->TT = pick_tt(p->t_out, 3, opts, 3); p->NT = d->c_out <= 192 ? 3 : 4; p->TH = 8;
+    // 12 accumulator tiles (NT 4 x TT 3) would spill: cap TT at 2 for the 256-wide image
+    p->family = 2; p->NT = d->c_out <= 192 ? 3 : 4; p->TT = pick_tt(p->t_out, p->NT == 4 ? 2 : 3); p->TH = 4;
     p->BN = 64 * p->NT;
   }
-  p->tiles_w = ceil_div(d->w, 16);
+  p->tiles_w = ceil_div(d->w, 32);
   p->tiles_h = ceil_div(d->h, p->TH);
   p->t_blocks = ceil_div(p->t_out, p->TT);
   p->n_blocks = ceil_div(d->c_out, p->BN);
   return SFVOS_OK;
 }
 
-template <int DT, int TAPS, int TT, int MT, int NT, int WS, int WN>
+template <int DT, int TAPS, int TPS, int TT, int MT, int NT, int WS, int WN>
 static int launch(const ConvArgs& a, long long grid, hipStream_t stream) {
-  typedef ConvCfg<DT, TAPS, TT, MT, NT, WS, WN> C;
-  auto kern = conv3d_kernel<DT, TAPS, TT, MT, NT, WS, WN>;
+  typedef ConvCfg<DT, TAPS, TPS, TT, MT, NT, WS, WN> C;
+  auto kern = conv3d_kernel<DT, TAPS, TPS, TT, MT, NT, WS, WN>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -302,19 +316,19 @@ static int launch(const ConvArgs& a, long long grid, hipStream_t stream) {
 
 template <int DT, int TAPS>
 static int dispatch(const ConvPlan& p, const ConvArgs& a, long long grid, hipStream_t s) {
-#define SFVOS_CASE(F, TTv, MTv, NTv, WSv, WNv) \
-  if (p.family == F && p.TT == TTv && p.NT == NTv) return launch<DT, TAPS, TTv, MTv, NTv, WSv, WNv>(a, grid, s);
-  // narrow: 16x16 pixels x TT frames x 32 channels; each wave one 32-pixel M-tile, all frames
-  SFVOS_CASE(0, 1, 1, 1, 8, 1) SFVOS_CASE(0, 2, 1, 1, 8, 1) SFVOS_CASE(0, 3, 1, 1, 8, 1) SFVOS_CASE(0, 4, 1, 1, 8, 1)
-  SFVOS_CASE(0, 6, 1, 1, 8, 1) SFVOS_CASE(0, 8, 1, 1, 8, 1) SFVOS_CASE(0, 11, 1, 1, 8, 1)
+#define SFVOS_CASE(F, TPSv, TTv, MTv, NTv, WSv, WNv) \
+  if (p.family == F && p.TT == TTv && p.NT == NTv) return launch<DT, TAPS, TPSv, TTv, MTv, NTv, WSv, WNv>(a, grid, s);
+  // narrow: 8 rows x 32 px x TT frames x 32 channels; wave = one row, all frames
+  constexpr int NTPS = TAPS == 9 ? 9 : 1;
+  SFVOS_CASE(0, NTPS, 1, 1, 1, 8, 1) SFVOS_CASE(0, NTPS, 2, 1, 1, 8, 1) SFVOS_CASE(0, NTPS, 3, 1, 1, 8, 1)
+  SFVOS_CASE(0, NTPS, 4, 1, 1, 8, 1)
   if constexpr (TAPS == 1) {
-    // mid (lateral 32->64): 16x16 pixels x TT frames x 64 channels
-    SFVOS_CASE(1, 1, 2, 1, 4, 2) SFVOS_CASE(1, 2, 2, 1, 4, 2) SFVOS_CASE(1, 3, 2, 1, 4, 2) SFVOS_CASE(1, 4, 2, 1, 4, 2)
-    SFVOS_CASE(1, 6, 2, 1, 4, 2)
+    // mid (lateral 32->64): 8 rows x 32 px x TT frames x 64 channels
+    SFVOS_CASE(1, 1, 1, 2, 1, 4, 2) SFVOS_CASE(1, 1, 2, 2, 1, 4, 2) SFVOS_CASE(1, 1, 3, 2, 1, 4, 2)
   } else {
-    // wide: 8x16 pixels x TT frames x 192/256 channels
-    SFVOS_CASE(2, 1, 1, 3, 4, 2) SFVOS_CASE(2, 2, 1, 3, 4, 2) SFVOS_CASE(2, 3, 1, 3, 4, 2)
-    SFVOS_CASE(2, 1, 1, 4, 4, 2) SFVOS_CASE(2, 2, 1, 4, 4, 2) SFVOS_CASE(2, 3, 1, 4, 4, 2)
+    // wide: 4 rows x 32 px x TT frames x 192/256 channels, 3 taps per stage
+    SFVOS_CASE(2, 3, 1, 1, 3, 4, 2) SFVOS_CASE(2, 3, 2, 1, 3, 4, 2) SFVOS_CASE(2, 3, 3, 1, 3, 4, 2)
+    SFVOS_CASE(2, 3, 1, 1, 4, 4, 2) SFVOS_CASE(2, 3, 2, 1, 4, 4, 2)
   }
 #undef SFVOS_CASE
   set_error("conv: no kernel instance for family %d TT %d NT %d taps %d", p.family, p.TT, p.NT, TAPS);
@@ -337,7 +351,6 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
   int rc = make_plan(d, &p);
   if (rc != SFVOS_OK) return rc;
   SFVOS_REQUIRE(x && w_packed && y && zeros, "conv: null pointer");
-  SFVOS_REQUIRE(!(d->taps == 9 && p.family == 1), "conv: 3x3 conv with c_out == 64 has no kernel instance");
   SFVOS_REQUIRE(!(d->taps == 1 && p.family == 2), "conv: 1x1 conv with c_out > 64 has no kernel instance");
   ConvArgs a;
   a.x = (const char*)x; a.wp = (const char*)w_packed; a.bias = bias; a.y = (char*)y; a.stat_part = stat_part;
@@ -346,6 +359,7 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
   a.pad_t = d->pad_t; a.ld_x = d->ld_x; a.ld_y = d->ld_y; a.accumulate = d->accumulate;
   a.tiles_w = p.tiles_w; a.tiles_h = p.tiles_h; a.t_blocks = p.t_blocks; a.n_blocks = p.n_blocks;
   a.x_bs = d->x_batch_stride; a.y_bs = d->y_batch_stride;
+  { const char* dbg = getenv("SFVOS_CONV_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
   const long long grid = (long long)d->batch * p.t_blocks * p.n_blocks * p.tiles_h * p.tiles_w;
   SFVOS_REQUIRE(grid > 0 && grid < (1ll << 31), "conv: grid %lld out of range", grid);
   hipStream_t s = (hipStream_t)stream;

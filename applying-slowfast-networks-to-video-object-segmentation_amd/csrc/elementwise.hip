@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) void from_ndhwc_kernel(const char* __restrict_
 }
 
 // ---- weight packing -----------------------------------------------------------------------------
-// packed[cc][tap][dt][j][n][e]  (one 16-B chunk = CE reduction channels for one output channel n)
+// packed[cc][dt][tap][j][n][e]  (one 16-B chunk = CE reduction channels for one output channel n;
+// a conv stage (cc, dt, tap group) is one contiguous block)
 template <int DT, bool DGRAD>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, char* packed, int c_out,
                                                            int c_in, int kt, int taps) {
@@ -134,8 +135,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     const int e = (int)(k % CE); k /= CE;
     const int n = (int)(k % N); k /= N;
     const int j = (int)(k % 4); k /= 4;
-    const int dt = (int)(k % kt); k /= kt;
     const int tap = (int)(k % taps); k /= taps;
+    const int dt = (int)(k % kt); k /= kt;
     const int cc = (int)k;
     const int c = cc * CK + j * CE + e;
     float val;
@@ -148,27 +149,36 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 }
 
 // ---- batch norm ---------------------------------------------------------------------------------
-// Deterministic column sums of part[rows][ncol] (fixed order: 8 strided lanes, then a fixed tree).
+// Deterministic column sums of part[rows][ncol]: block = 32 channels x RL row lanes, each lane sums
+// its strided rows (4 loads in flight), then lane 0 adds the RL lane sums in a fixed order.
+constexpr int RL = 32;
 __device__ __forceinline__ double column_sum(const float* part, int rows, int ncol, int col, int sub, double* scratch,
                                              int c_local) {
-  double s = 0.0;
-  for (int rI = sub; rI < rows; rI += 8) s += (double)part[(long long)rI * ncol + col];
-  scratch[sub * 32 + c_local] = s;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int rI = sub;
+  for (; rI + 3 * RL < rows; rI += 4 * RL) {
+    s0 += (double)part[(long long)rI * ncol + col];
+    s1 += (double)part[(long long)(rI + RL) * ncol + col];
+    s2 += (double)part[(long long)(rI + 2 * RL) * ncol + col];
+    s3 += (double)part[(long long)(rI + 3 * RL) * ncol + col];
+  }
+  for (; rI < rows; rI += RL) s0 += (double)part[(long long)rI * ncol + col];
+  scratch[sub * 32 + c_local] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   double tot = 0.0;
   if (sub == 0)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) tot += scratch[k * 32 + c_local];
+    for (int k = 0; k < RL; ++k) tot += scratch[k * 32 + c_local];
   __syncthreads();
   return tot;
 }
 
-// block = 256 threads = 32 channels x 8 row-lanes; grid = C/32
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* part, int rows, double count,
+// block = 32 channels x RL row lanes; grid = C/32
+__global__ __launch_bounds__(32 * RL) void bn_finalize_kernel(const float* part, int rows, double count,
                                                           const float* gamma, const float* beta, float eps, int C,
                                                           float* mean, float* rstd, float* scale, float* shift,
                                                           float* var_unbiased) {
-  __shared__ double scratch[256];
+  __shared__ double scratch[32 * RL];
   const int c_local = threadIdx.x & 31, sub = threadIdx.x >> 5, c = blockIdx.x * 32 + c_local;
   const double s1 = column_sum(part, rows, 2 * C, c, sub, scratch, c_local);
   const double s2 = column_sum(part, rows, 2 * C, C + c, sub, scratch, c_local);
@@ -303,12 +313,12 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_bwd_kernel(
 }
 
 // dgamma/dbeta and the pass-2 coefficients.  block = 32 channels x 8 row lanes.
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part, int rows, double count,
+__global__ __launch_bounds__(32 * RL) void bn_bwd_finalize_kernel(const float* part, int rows, double count,
                                                               const float* gamma, const float* mean,
                                                               const float* rstd, int C, int train, int accumulate,
                                                               float* dgamma, float* dbeta, float* cA, float* cB,
                                                               float* cK) {
-  __shared__ double scratch[256];
+  __shared__ double scratch[32 * RL];
   const int c_local = threadIdx.x & 31, sub = threadIdx.x >> 5, c = blockIdx.x * 32 + c_local;
   const double sdz = column_sum(part, rows, 2 * C, c, sub, scratch, c_local);
   const double sdzx = column_sum(part, rows, 2 * C, C + c, sub, scratch, c_local);
@@ -329,9 +339,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* part,
   }
 }
 
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* part, int rows, int C, float* out,
+__global__ __launch_bounds__(32 * RL) void reduce_rows_kernel(const float* part, int rows, int C, float* out,
                                                           int accumulate) {
-  __shared__ double scratch[256];
+  __shared__ double scratch[32 * RL];
   const int c_local = threadIdx.x & 31, sub = threadIdx.x >> 5, c = blockIdx.x * 32 + c_local;
   const double s = column_sum(part, rows, C, c < C ? c : 0, sub, scratch, c_local);
   if (sub == 0 && c < C) out[c] = (accumulate ? out[c] : 0.f) + (float)s;
@@ -451,7 +461,7 @@ extern "C" int sfvos_bn_finalize(const float* part, int rows, int64_t count, con
                                  float* save_var_unbiased, sfvos_stream_t stream) {
   SFVOS_REQUIRE(part && gamma && beta && mean && rstd && scale && shift && save_var_unbiased, "bn_finalize: null");
   SFVOS_REQUIRE(rows > 0 && count > 0 && C > 0 && C % 32 == 0, "bn_finalize: bad rows/count/C");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 32), dim3(256), 0, (hipStream_t)stream, part, rows, (double)count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C / 32), dim3(32 * RL), 0, (hipStream_t)stream, part, rows, (double)count,
                      gamma, beta, eps, C, mean, rstd, scale, shift, save_var_unbiased);
   return check_launch("bn_finalize");
 }
@@ -528,7 +538,7 @@ extern "C" int sfvos_bn_bwd_finalize(const float* part, int rows, int64_t count,
                                      float* coefA, float* coefB, float* coefK, sfvos_stream_t stream) {
   SFVOS_REQUIRE(part && gamma && mean && rstd && coefA && coefB && coefK, "bn_bwd_finalize: null pointer");
   SFVOS_REQUIRE(rows > 0 && count > 0 && C > 0 && C % 32 == 0, "bn_bwd_finalize: bad rows/count/C");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 32), dim3(256), 0, (hipStream_t)stream, part, rows,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 32), dim3(32 * RL), 0, (hipStream_t)stream, part, rows,
                      (double)count, gamma, mean, rstd, C, train, accumulate, dgamma, dbeta, coefA, coefB, coefK);
   return check_launch("bn_bwd_finalize");
 }
@@ -558,7 +568,7 @@ extern "C" int sfvos_bn_bwd_apply(const void* dy, int ld_dy, const void* x, int 
 extern "C" int sfvos_reduce_rows(const float* part, int rows, int C, float* out, int accumulate,
                                  sfvos_stream_t stream) {
   SFVOS_REQUIRE(part && out && rows > 0 && C > 0, "reduce_rows: bad argument");
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream, part, rows, C, out,
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(C, 32)), dim3(32 * RL), 0, (hipStream_t)stream, part, rows, C, out,
                      accumulate);
   return check_launch("reduce_rows");
 }

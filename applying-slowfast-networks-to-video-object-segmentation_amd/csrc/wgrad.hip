@@ -3,18 +3,21 @@
 //
 //   dW[n][c][dt][tap] = sum_{b,t,h,w} dy[b,t,h,w,n] * x[b,t+dt,h+dh-1,w+dw-1,c]
 //
-// GEMM view: D[n (32 rows)][c (32 cols)] += A[n][k = pixel] * B[k = pixel][c], the reduction runs
+// GEMM view: D[n (32 rows)][c (32 cols)] += A[n][k = pixel] * B[k = pixel][c]; the reduction runs
 // over pixels, so BOTH operands are "k-major" in NDHWC.  bf16: tiles sit in LDS as
 // [pixel][32 channels] (64-B rows) and are read with ds_read_b64_tr_b16 (hardware transpose: a
 // half-wave touches 4 consecutive 64-B rows = one 256-B bank row, conflict-free); f32: the exact
 // 32x32x2 MFMA takes one scalar per lane, read with ds_read_b32 (32 consecutive floats per half).
 //
-// One workgroup (8 waves) owns NTN n-tiles x NTC c-tiles x DG temporal taps x all spatial taps
-// (wave = one (n-tile, c-tile, dt) group, TAPS accumulator tiles) and walks a contiguous share
-// of the (clip, frame, TH x 16 pixel tile) stages: per stage the dy tile and the DG x NTC halo
-// tiles of x are DMA'd into LDS (double-buffered, one barrier per stage).  Split-K partials go
-// to fp32 slabs, summed in a fixed order by wgrad_reduce_kernel (deterministic, no atomics),
-// which also transposes into the state-dict layout [Cout][Cin][kt][kh][kw].
+// One workgroup (8 waves) owns NTN n-tiles x NTC c-tiles x DG temporal taps x all spatial taps;
+// wave = one (n-tile, c-tile, dt) group with TAPS accumulator tiles.  It sweeps its share of the
+// TH x 16 pixel tiles; for each tile it walks the input frames t: stage (tile, t) holds the halo
+// tile of x[t] (double-buffered) and a ring of the DG+1 newest dy frames, so x[t] is paired with
+// dy[t-dt] for all DG taps of the group from ONE load (x traffic / DG), and exactly one x tile +
+// one dy frame are DMA'd per stage (global_load_lds, one barrier per stage).
+// Split-K partials go to fp32 slabs, summed in a fixed order by wgrad_reduce_kernel
+// (deterministic, no atomics), which also transposes into the state-dict layout
+// [Cout][Cin][kt][kh][kw].
 #include "common.h"
 
 namespace sfvos {
@@ -27,7 +30,7 @@ struct WgradArgs {
   int t_in, t_out, H, W, c_in, c_out, kt, ld_x, ld_y, batch;
   int tiles_w, tiles_h, n_blocks, c_blocks, dt_blocks, psplit;
   long long x_bs, y_bs;
-  long long nstages;  // batch * t_out * tiles_h * tiles_w
+  int ntiles;  // batch * tiles_h * tiles_w
 };
 
 template <int DT, int TAPS, int NTN, int NTC, int DG, int TH>
@@ -38,20 +41,24 @@ struct WgradCfg {
   static constexpr int HALO = TAPS == 9 ? 1 : 0;
   static constexpr int HR = TH + 2 * HALO, HC = 16 + 2 * HALO;
   static constexpr int NPOS = TH * 16, NHPOS = HR * HC;
-  static constexpr int DY_SLOTS = NTN * NPOS * SPP;
-  static constexpr int X_SLOTS = DG * NTC * NHPOS * SPP;
-  static constexpr int STAGE_BYTES = (DY_SLOTS + X_SLOTS) * 16;
-  static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+  static constexpr int R = DG + 1;               // dy ring slots
+  static constexpr int DY_SLOTS = NTN * NPOS * SPP;   // one dy frame
+  static constexpr int X_SLOTS = NTC * NHPOS * SPP;   // one x halo tile
+  static constexpr int DY_BYTES = DY_SLOTS * 16, X_BYTES = X_SLOTS * 16;
+  static constexpr int LDS_BYTES = 2 * X_BYTES + R * DY_BYTES;
   static_assert(NTN * NTC * DG == 8, "one (n-tile, c-tile, dt) group per wave");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-__device__ __forceinline__ u32x4 tr_read_pair(const char* p0, const char* p1) {
-  // two ds_read_b64_tr_b16: k = 0..3 and k = 4..7 of this lane's half of the k-step
-  const short4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SFVOS_LDS short4v*)p0);
-  const short4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SFVOS_LDS short4v*)p1);
-  typedef __attribute__((ext_vector_type(8))) short short8v;
-  short8v v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-  return __builtin_bit_cast(u32x4, v);
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+__device__ __forceinline__ u32x2 tr_read(const char* p) {
+  const short4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((SFVOS_LDS short4v*)p);
+  return __builtin_bit_cast(u32x2, a);
+}
+__device__ __forceinline__ u32x4 join(const u32x2& lo, const u32x2& hi) {
+  u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+  return v;
 }
 
 template <int DT, int TAPS, int NTN, int NTC, int DG, int TH>
@@ -59,6 +66,8 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
   typedef WgradCfg<DT, TAPS, NTN, NTC, DG, TH> C;
   constexpr int CE = C::CE, ES = 16 / CE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const xbase = smem;
+  char* const dybase = smem + 2 * C::X_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = wv % NTN, ct = (wv / NTN) % NTC, dg = wv / (NTN * NTC);
@@ -70,10 +79,13 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
   const int cb = bid % a.c_blocks; bid /= a.c_blocks;
   const int db = bid;
   const int n_base = nb * NTN * 32, c_base = cb * NTC * 32, dt0 = db * DG;
+  const int dt_live = min(DG, a.kt - dt0);      // temporal taps of this group that exist
+  const int nfr = a.t_out + dt_live - 1;        // input frames per tile: t = dt0 .. dt0 + nfr - 1
 
-  const long long per = (a.nstages + a.psplit - 1) / a.psplit;
-  const long long s_begin = (long long)ps * per;
-  const long long s_end = s_begin + per < a.nstages ? s_begin + per : a.nstages;
+  const int per = (a.ntiles + a.psplit - 1) / a.psplit;
+  const int tile_begin = ps * per;
+  const int tile_end = min(a.ntiles, tile_begin + per);
+  const int S = max(0, tile_end - tile_begin) * nfr;
 
   f32x16 acc[TAPS];
 #pragma unroll
@@ -81,65 +93,84 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
-  const bool wave_live = (n_base + nt * 32 < a.c_out) && (c_base + ct * 32 < a.c_in) && (dt0 + dg < a.kt);
+  const bool wave_live = (n_base + nt * 32 < a.c_out) && (c_base + ct * 32 < a.c_in) && (dg < dt_live);
 
-  auto issue = [&](long long st, int buf) {
-    long long k = st;
-    const int tw = (int)(k % a.tiles_w); k /= a.tiles_w;
-    const int th = (int)(k % a.tiles_h); k /= a.tiles_h;
-    const int to = (int)(k % a.t_out); k /= a.t_out;
-    const int b = (int)k;
+  // stage s -> (tile, frame index fi); DMA of x[t = dt0 + fi] halo tile and dy frame fi
+  auto issue = [&](int s) {
+    const int tile = tile_begin + s / nfr, fi = s % nfr;
+    int k = tile;
+    const int tw = k % a.tiles_w; k /= a.tiles_w;
+    const int th = k % a.tiles_h; k /= a.tiles_h;
+    const int b = k;
     const int h0 = th * TH, w0 = tw * 16;
-    char* dyb = smem + buf * C::STAGE_BYTES;
-    char* xb = dyb + C::DY_SLOTS * 16;
-    const char* dyf = a.dy + ((long long)b * a.y_bs + (long long)to * a.H * a.W * a.ld_y) * ES;
+    const int t = dt0 + fi;
+    char* xb = xbase + (s & 1) * C::X_BYTES;
+    char* dyb = dybase + (s % C::R) * C::DY_BYTES;
+    const bool dy_ok = fi < a.t_out;
+    const char* dyf = a.dy + ((long long)b * a.y_bs + (long long)fi * a.H * a.W * a.ld_y) * ES;
 #pragma unroll
     for (int it = 0; it < (C::DY_SLOTS + 511) / 512; ++it) {
       const int sl = it * 512 + tid;
       if (sl < C::DY_SLOTS) {
         const int j = sl % C::SPP, pos = (sl / C::SPP) % C::NPOS, tnt = sl / (C::SPP * C::NPOS);
         const int h = h0 + pos / 16, w = w0 + pos % 16, n = n_base + tnt * 32;
-        const bool ok = h < a.H && w < a.W && n < a.c_out;
+        const bool ok = dy_ok && h < a.H && w < a.W && n < a.c_out;
         const char* src = ok ? dyf + ((long long)(h * a.W + w) * a.ld_y + n + j * CE) * ES : a.zeros;
         glds16(src, dyb + (sl - lane) * 16);
       }
     }
+    const bool x_ok = t < a.t_in;
+    const char* xf = a.x + ((long long)b * a.x_bs + (long long)t * a.H * a.W * a.ld_x) * ES;
 #pragma unroll
     for (int it = 0; it < (C::X_SLOTS + 511) / 512; ++it) {
       const int sl = it * 512 + tid;
       if (sl < C::X_SLOTS) {
-        const int j = sl % C::SPP, hp = (sl / C::SPP) % C::NHPOS, grp = sl / (C::SPP * C::NHPOS);
-        const int tct = grp % NTC, tdg = grp / NTC;
-        const int h = h0 + hp / C::HC - C::HALO, w = w0 + hp % C::HC - C::HALO;
-        const int c = c_base + tct * 32, dt = dt0 + tdg;
-        const bool ok = (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && c < a.c_in && dt < a.kt;
-        const char* src =
-            ok ? a.x + ((long long)b * a.x_bs + ((long long)(to + dt) * a.H * a.W + (long long)h * a.W + w) * a.ld_x +
-                        c + j * CE) * ES
-               : a.zeros;
+        const int j = sl % C::SPP, hp = (sl / C::SPP) % C::NHPOS, tct = sl / (C::SPP * C::NHPOS);
+        const int h = h0 + hp / C::HC - C::HALO, w = w0 + hp % C::HC - C::HALO, c = c_base + tct * 32;
+        const bool ok = x_ok && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && c < a.c_in;
+        const char* src = ok ? xf + ((long long)(h * a.W + w) * a.ld_x + c + j * CE) * ES : a.zeros;
         glds16(src, xb + (sl - lane) * 16);
       }
     }
   };
 
-  auto compute = [&](int buf) {
-    const char* dyb = smem + buf * C::STAGE_BYTES + nt * (C::NPOS * C::ROWB);
-    const char* xb = smem + buf * C::STAGE_BYTES + C::DY_SLOTS * 16 + (dg * NTC + ct) * (C::NHPOS * C::ROWB);
+  auto compute = [&](int s) {
+    // this wave pairs x[t] with dy[t - dt0 - dg], which entered the ring dg stages ago
+    const char* dyb = dybase + ((s - dg + C::R) % C::R) * C::DY_BYTES + nt * (C::NPOS * C::ROWB);
+    const char* xb = xbase + (s & 1) * C::X_BYTES + ct * (C::NHPOS * C::ROWB);
     if constexpr (DT == SFVOS_BF16) {
-      // lane -> (row q, 4-column group p) of its 16-lane group's 4x16 block; block = rows k0..k0+3
+      // lane -> (row q, 4-column group p) of its 16-lane group's 4x16 block; block rows k0..k0+3
       const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
       const int lane_off = (8 * (g >> 1) + q) * C::ROWB + (16 * (g & 1) + 4 * p) * 2;
-#pragma unroll
-      for (int ty = 0; ty < TH; ++ty) {
-        const char* ap = dyb + ty * 16 * C::ROWB + lane_off;
-        const u32x4 av = tr_read_pair(ap, ap + 4 * C::ROWB);
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-          const int dh = TAPS == 9 ? tap / 3 : 0, dw = TAPS == 9 ? tap % 3 : 0;
-          const char* bp = xb + ((ty + dh) * C::HC + dw) * C::ROWB + lane_off;
-          const u32x4 bv = tr_read_pair(bp, bp + 4 * C::ROWB);
-          Mma<SFVOS_BF16>::run(acc[tap], av, bv);
+      constexpr int TROWS = TAPS == 9 ? 3 : 1, TCOLS = TAPS == 9 ? 3 : 1;
+      // step = (ty, dh): one A fragment per ty, TCOLS B fragments per step; the next step's
+      // fragments are read while this step's MFMAs run (order pinned with sched_barrier)
+      u32x2 ar[2][2], br[2][TCOLS][2];
+      auto load = [&](int step, int buf) {
+        const int ty = step / TROWS, dh = step % TROWS;
+        if (dh == 0) {
+          const char* ap = dyb + ty * 16 * C::ROWB + lane_off;
+          ar[ty & 1][0] = tr_read(ap);
+          ar[ty & 1][1] = tr_read(ap + 4 * C::ROWB);
         }
+#pragma unroll
+        for (int dw = 0; dw < TCOLS; ++dw) {
+          const char* bp = xb + ((ty + dh) * C::HC + dw) * C::ROWB + lane_off;
+          br[buf][dw][0] = tr_read(bp);
+          br[buf][dw][1] = tr_read(bp + 4 * C::ROWB);
+        }
+      };
+      load(0, 0);
+#pragma unroll
+      for (int step = 0; step < TH * TROWS; ++step) {
+        if (step + 1 < TH * TROWS) load(step + 1, (step + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int ty = step / TROWS, dh = step % TROWS;
+        const u32x4 av = join(ar[ty & 1][0], ar[ty & 1][1]);
+#pragma unroll
+        for (int dw = 0; dw < TCOLS; ++dw)
+          Mma<SFVOS_BF16>::run(acc[dh * TCOLS + dw], av, join(br[step & 1][dw][0], br[step & 1][dw][1]));
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
 #pragma unroll
@@ -158,13 +189,13 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
     }
   };
 
-  if (s_begin < s_end) issue(s_begin, 0);
-  for (long long st = s_begin; st < s_end; ++st) {
-    const int buf = (int)((st - s_begin) & 1);
+  if (S > 0) issue(0);
+  for (int s = 0; s < S; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (st + 1 < s_end) issue(st + 1, buf ^ 1);
-    if (wave_live) compute(buf);
+    if (s + 1 < S) issue(s + 1);
+    const int fo = s % nfr - dg;  // dy frame this wave pairs with x[t] at this stage
+    if (wave_live && fo >= 0 && fo < a.t_out) compute(s);
   }
 
   // slab[ps][n][dt][tap][c]
@@ -181,6 +212,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
 }
 
 // grad_w[n][c][dt][tap] (=|+=) sum_ps slab[ps][n][dt][tap][c]
+// block = 64 consecutive c x 4 (n,dt,tap) rows: coalesced slab reads along c.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int psplit, int c_out,
                                                            int c_in, int kt, int taps, float* grad_w, int accumulate) {
   const long long total = (long long)c_out * c_in * kt * taps;
@@ -190,18 +222,25 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int tap = (int)(k % taps); k /= taps;
     const int dt = (int)(k % kt); k /= kt;
     const int n = (int)k;
-    float s = 0.f;
-    for (int p = 0; p < psplit; ++p) s += slab[(long long)p * total + i];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 4 <= psplit; p += 4) {
+      s0 += slab[(long long)p * total + i];
+      s1 += slab[(long long)(p + 1) * total + i];
+      s2 += slab[(long long)(p + 2) * total + i];
+      s3 += slab[(long long)(p + 3) * total + i];
+    }
+    for (; p < psplit; ++p) s0 += slab[(long long)p * total + i];
+    const float s = (s0 + s1) + (s2 + s3);
     float* dst = grad_w + (((long long)n * c_in + c) * kt + dt) * taps + tap;
     *dst = accumulate ? *dst + s : s;
   }
 }
 
 struct WgradPlan {
-  int cfg;  // 0: A (1,8,1) 3x3 ; 1: B (4,2,1) 3x3 ; 2: C (1,1,8) 3x3 ; 3: D (2,1,4) 1x1
+  int cfg;  // 0: (1,2,4) 3x3 narrow-n ; 1: (2,2,2) 3x3 ; 2: (1,1,8) 3x3 c_in 32 ; 3: (2,1,4) 1x1
   int NTN, NTC, DG, TH;
-  int tiles_w, tiles_h, n_blocks, c_blocks, dt_blocks, psplit, t_out;
-  long long nstages;
+  int tiles_w, tiles_h, n_blocks, c_blocks, dt_blocks, psplit, t_out, ntiles;
 };
 
 static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
@@ -216,28 +255,27 @@ static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
   SFVOS_REQUIRE(p->t_out >= 1, "wgrad: kt > t_in");
   const bool f32 = d->dtype == SFVOS_F32;
   if (d->taps == 1) {
-    p->cfg = 3; p->NTN = 2; p->NTC = 1; p->DG = 4; p->TH = f32 ? 4 : 8;
-  } else if (d->c_out <= 32 && d->c_in >= 256) {
-    p->cfg = 0; p->NTN = 1; p->NTC = 8; p->DG = 1; p->TH = f32 ? 2 : 4;
+    p->cfg = 3; p->NTN = 2; p->NTC = 1; p->DG = 4;
   } else if (d->c_in <= 32) {
-    p->cfg = 2; p->NTN = 1; p->NTC = 1; p->DG = 8; p->TH = f32 ? 2 : 4;
+    p->cfg = 2; p->NTN = 1; p->NTC = 1; p->DG = 8;
+  } else if (d->c_out <= 32) {
+    p->cfg = 0; p->NTN = 1; p->NTC = 2; p->DG = 4;
   } else {
-    p->cfg = 1; p->NTN = 4; p->NTC = 2; p->DG = 1; p->TH = 4;
+    p->cfg = 1; p->NTN = 2; p->NTC = 2; p->DG = 2;
   }
+  p->TH = f32 ? 4 : 8;
   p->tiles_w = ceil_div(d->w, 16);
   p->tiles_h = ceil_div(d->h, p->TH);
   p->n_blocks = ceil_div(d->c_out, 32 * p->NTN);
   p->c_blocks = ceil_div(d->c_in, 32 * p->NTC);
   p->dt_blocks = ceil_div(d->kt, p->DG);
-  p->nstages = (long long)d->batch * p->t_out * p->tiles_h * p->tiles_w;
+  p->ntiles = d->batch * p->tiles_h * p->tiles_w;
   const int col_blocks = p->n_blocks * p->c_blocks * p->dt_blocks;
-  long long ps = ceil_div64(1024, col_blocks);  // ~4 workgroups per CU in flight over the launch
-  if (ps > p->nstages) ps = p->nstages;
+  int ps = ceil_div(768, col_blocks);  // ~3 workgroups per CU over the launch
+  if (ps > p->ntiles) ps = p->ntiles;
   if (ps < 1) ps = 1;
-  // no empty splits: every ps must own >= 1 stage
-  const long long per = ceil_div64(p->nstages, ps);
-  ps = ceil_div64(p->nstages, per);
-  p->psplit = (int)ps;
+  const int per = ceil_div(p->ntiles, ps);  // no empty splits
+  p->psplit = ceil_div(p->ntiles, per);
   return SFVOS_OK;
 }
 
@@ -280,20 +318,20 @@ extern "C" int sfvos_conv3d_wgrad(const sfvos_conv_desc* d, const void* x, const
   a.ld_x = d->ld_x; a.ld_y = d->ld_y; a.batch = d->batch;
   a.tiles_w = p.tiles_w; a.tiles_h = p.tiles_h; a.n_blocks = p.n_blocks; a.c_blocks = p.c_blocks;
   a.dt_blocks = p.dt_blocks; a.psplit = p.psplit; a.x_bs = d->x_batch_stride; a.y_bs = d->y_batch_stride;
-  a.nstages = p.nstages;
+  a.ntiles = p.ntiles;
   const long long grid = (long long)p.psplit * p.n_blocks * p.c_blocks * p.dt_blocks;
   hipStream_t s = (hipStream_t)stream;
   const bool bf = d->dtype == SFVOS_BF16;
   switch (p.cfg) {
-    case 0: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 1, 8, 1, 4>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 1, 8, 1, 2>(a, grid, s); break;
-    case 1: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 4, 2, 1, 4>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 4, 2, 1, 4>(a, grid, s); break;
-    case 2: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 1, 1, 8, 4>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 1, 1, 8, 2>(a, grid, s); break;
+    case 0: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 1, 2, 4, 8>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 1, 2, 4, 4>(a, grid, s); break;
+    case 1: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 2, 2, 2, 8>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 2, 2, 2, 4>(a, grid, s); break;
+    case 2: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 1, 1, 8, 8>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 1, 1, 8, 4>(a, grid, s); break;
     default: rc = bf ? launch_wgrad<SFVOS_BF16, 1, 2, 1, 4, 8>(a, grid, s) : launch_wgrad<SFVOS_F32, 1, 2, 1, 4, 4>(a, grid, s); break;
   }
   if (rc != SFVOS_OK) return rc;
   const long long total = (long long)d->c_out * d->c_in * d->kt * d->taps;
   long long rgrid = ceil_div64(total, 256);
-  if (rgrid > 4096) rgrid = 4096;
+  if (rgrid > 8192) rgrid = 8192;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rgrid), dim3(256), 0, s, (const float*)workspace, p.psplit,
                      d->c_out, d->c_in, d->kt, d->taps, grad_w, accumulate);
   return check_launch("wgrad_reduce");
