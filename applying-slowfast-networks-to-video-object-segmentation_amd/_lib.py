@@ -9,16 +9,48 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SFVOS_LIB') or os.path.join(_HERE, 'csrc', 'libsfvos.so')  # SFVOS_LIB: A/B builds
 
 F32, BF16 = 0, 1
+MAX_LEVELS = 8
 
-vp, i32, i64, f32, fp = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_void_p
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class Pyramid(C.Structure):
+    """Mirror of sfvos_pyramid."""
+    _fields_ = [('n_levels', i32), ('h', i32 * MAX_LEVELS), ('w', i32 * MAX_LEVELS)]
+
+
+class Levels(C.Structure):
+    """Mirror of sfvos_levels: positions per level of a flat pyramid buffer."""
+    _fields_ = [('n_levels', i32), ('m', i64 * MAX_LEVELS)]
 
 
 class ConvDesc(C.Structure):
     """Mirror of sfvos_conv_desc (include/sfvos.h)."""
-    _fields_ = [('dtype', i32), ('batch', i32), ('t_in', i32), ('h', i32), ('w', i32), ('c_in', i32), ('c_out', i32),
-                ('kt', i32), ('taps', i32), ('pad_t', i32), ('ld_x', i32), ('ld_y', i32), ('accumulate', i32),
-                ('x_batch_stride', i64), ('y_batch_stride', i64)]
+    _fields_ = [('dtype', i32), ('batch', i32), ('t_in', i32), ('t_alloc', i32), ('t_offset', i32), ('c_in', i32),
+                ('c_out', i32), ('kt', i32), ('taps', i32), ('pad_t', i32), ('ld_x', i32), ('ld_y', i32),
+                ('accumulate', i32), ('pyr', Pyramid)]
 
+
+def make_pyramid(shapes):
+    """shapes: list of (H, W) per level."""
+    if not 1 <= len(shapes) <= MAX_LEVELS:
+        raise ValueError('a pyramid has 1..%d levels, got %d' % (MAX_LEVELS, len(shapes)))
+    p = Pyramid()
+    p.n_levels = len(shapes)
+    for l, (h, w) in enumerate(shapes):
+        p.h[l], p.w[l] = int(h), int(w)
+    return p
+
+
+def make_levels(shapes, batch, frames):
+    lv = Levels()
+    lv.n_levels = len(shapes)
+    for l, (h, w) in enumerate(shapes):
+        lv.m[l] = int(batch) * int(frames) * int(h) * int(w)
+    return lv
+
+
+PD, PL = C.POINTER(ConvDesc), C.POINTER(Levels)
 
 # name -> (restype, argtypes); every symbol include/sfvos.h declares
 SIGNATURES = {
@@ -32,18 +64,18 @@ SIGNATURES = {
     'sfvos_packed_weight_bytes': (C.c_size_t, [i32, i32, i32, i32, i32]),
     'sfvos_pack_weights_fwd': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     'sfvos_pack_weights_dgrad': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
-    'sfvos_conv3d_stat_rows': (i32, [C.POINTER(ConvDesc)]),
-    'sfvos_conv3d': (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]),
-    'sfvos_conv3d_wgrad_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
-    'sfvos_conv3d_wgrad': (i32, [C.POINTER(ConvDesc), vp, vp, vp, i32, vp, vp, vp]),
-    'sfvos_bn_finalize': (i32, [vp, i32, i64, vp, vp, f32, i32, vp, vp, vp, vp, vp, vp]),
-    'sfvos_bn_eval_coeffs': (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp]),
-    'sfvos_bn_running_update': (i32, [vp, vp, vp, vp, i32, i32, f32, vp]),
-    'sfvos_bn_apply': (i32, [vp, i32, vp, i32, i32, i64, i32, vp, vp, i32, vp]),
-    'sfvos_bn_bwd_rows': (i32, [i64]),
-    'sfvos_bn_bwd_reduce': (i32, [vp, i32, vp, i32, i32, i64, i32, vp, vp, vp, vp, i32, vp, vp]),
-    'sfvos_bn_bwd_finalize': (i32, [vp, i32, i64, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
-    'sfvos_bn_bwd_apply': (i32, [vp, i32, vp, i32, vp, i32, i32, i64, i32, vp, vp, i32, vp, vp, vp, vp, vp]),
+    'sfvos_conv3d_stat_rows': (i32, [PD, C.POINTER(i32)]),
+    'sfvos_conv3d': (i32, [PD, vp, vp, vp, vp, vp, vp, vp]),
+    'sfvos_conv3d_wgrad_workspace_bytes': (C.c_size_t, [PD]),
+    'sfvos_conv3d_wgrad': (i32, [PD, vp, vp, vp, i32, vp, vp, vp]),
+    'sfvos_bn_finalize': (i32, [vp, i32, C.POINTER(i32), C.POINTER(i64), vp, vp, f32, i32, vp, vp, vp, vp, vp, i32, vp]),
+    'sfvos_bn_eval_coeffs': (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp]),
+    'sfvos_bn_running_update': (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp]),
+    'sfvos_bn_apply': (i32, [vp, i32, vp, i32, i32, PL, i32, vp, vp, i32, i32, vp]),
+    'sfvos_bn_bwd_rows': (i32, [PL]),
+    'sfvos_bn_bwd_reduce': (i32, [vp, i32, vp, i32, i32, PL, i32, vp, vp, vp, vp, i32, i32, vp, vp]),
+    'sfvos_bn_bwd_finalize': (i32, [vp, PL, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    'sfvos_bn_bwd_apply': (i32, [vp, i32, vp, i32, vp, i32, i32, PL, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     'sfvos_reduce_rows': (i32, [vp, i32, i32, vp, i32, vp]),
     'sfvos_sgd_step': (i32, [vp, vp, vp, i64, f32, f32, f32, i32, vp]),
     'sfvos_scale': (i32, [vp, i64, f32, vp]),

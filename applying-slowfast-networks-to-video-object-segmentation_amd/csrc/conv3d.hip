@@ -1,7 +1,8 @@
-// conv3d.hip -- kt x 3 x 3 (pad 0,1,1) and k x 1 x 1 3D convolution, NDHWC, as an implicit GEMM
-// on the gfx950 matrix cores.  Replaces aten::convolution at reference
+// conv3d.hip -- kt x 3 x 3 (pad 0,1,1) and k x 1 x 1 3D convolution, pyramid NDHWC, as an implicit
+// GEMM on the gfx950 matrix cores.  Replaces aten::convolution at reference
 // code/helpers/model.py:112,120,124,132,136,144,147; with a flipped weight image and
 // pad_t = kt-1 the same kernel is aten::convolution_backward's grad_input.
+// ONE launch covers every FPN level of temporally_enhance_features (model.py:156-163).
 //
 // Decomposition (one workgroup = 8 waves, 2 per SIMD):
 //   output tile  = TT output frames x (TH rows x 32 px) x BN output channels, f32 accumulators
@@ -16,7 +17,8 @@
 //   LDS images   : chunk-major [16B chunk][row][col] and [tap][chunk][n]: every ds_read_b128 of an
 //                  MFMA operand covers 32 consecutive 16-B slots per half-wave -> conflict-free.
 //   inner loop   : branch-free: per (tap, k-step) NT B-fragment + TT*MT A-fragment reads feed
-//                  TT*MT*NT MFMAs (32x32x16 bf16, or 4 x 32x32x2 exact f32).
+//                  TT*MT*NT MFMAs (32x32x16 bf16, or 4 x 32x32x2 exact f32); the reads of step k+1
+//                  are pinned ahead of the MFMAs of step k.
 //   epilogue     : + bias, optional += y, store as dtype, per-channel (sum, sumsq) of the tile
 //                  written as one deterministic partial row per workgroup (BN statistics).
 #include <stdlib.h>
@@ -25,6 +27,15 @@
 
 namespace sfvos {
 
+struct ConvLevels {
+  int n;
+  int H[SFVOS_MAX_LEVELS], W[SFVOS_MAX_LEVELS], tiles_h[SFVOS_MAX_LEVELS], tiles_w[SFVOS_MAX_LEVELS];
+  int wg_begin[SFVOS_MAX_LEVELS + 1];   // first workgroup of each level
+  int row_begin[SFVOS_MAX_LEVELS + 1];  // first statistics row of each level
+  long long xpos[SFVOS_MAX_LEVELS];     // first position of the level in the x / y pyramid buffers
+  long long ypos[SFVOS_MAX_LEVELS];
+};
+
 struct ConvArgs {
   const char* x;
   const char* wp;
@@ -32,10 +43,10 @@ struct ConvArgs {
   char* y;
   float* stat_part;
   const char* zeros;
-  int t_in, t_out, H, W, c_in, c_out, kt, pad_t, ld_x, ld_y, accumulate;
-  int tiles_w, tiles_h, t_blocks, n_blocks;
-  long long x_bs, y_bs;
+  int batch, t_in, t_alloc, t_offset, t_out, c_in, c_out, kt, pad_t, ld_x, ld_y, accumulate;
+  int t_blocks, n_blocks;
   int debug;  // timing-only: bit0 skip compute, bit1 skip DMA after the first stage (results wrong)
+  ConvLevels lv;
 };
 
 template <int DT, int TAPS, int TPS, int TT, int MT, int NT, int WS, int WN>
@@ -70,9 +81,15 @@ __global__ __launch_bounds__(64 * WS * WN) void conv3d_kernel(ConvArgs a) {
   const int ws = wv % WS, wn = wv / WS;
   const int r = lane & 31, hh = lane >> 5;
 
-  int bid = blockIdx.x;
-  const int tw = bid % a.tiles_w; bid /= a.tiles_w;
-  const int th = bid % a.tiles_h; bid /= a.tiles_h;
+  // workgroup -> (level, clip, frame block, channel block, pixel tile)
+  int lvl = 0;
+#pragma unroll
+  for (int l = 1; l < SFVOS_MAX_LEVELS; ++l)
+    if (l < a.lv.n && (int)blockIdx.x >= a.lv.wg_begin[l]) lvl = l;
+  const int H = a.lv.H[lvl], W = a.lv.W[lvl], tiles_w = a.lv.tiles_w[lvl], tiles_h = a.lv.tiles_h[lvl];
+  int bid = blockIdx.x - a.lv.wg_begin[lvl];
+  const int tw = bid % tiles_w; bid /= tiles_w;
+  const int th = bid % tiles_h; bid /= tiles_h;
   const int nb = bid % a.n_blocks; bid /= a.n_blocks;
   const int tb = bid % a.t_blocks; bid /= a.t_blocks;
   const int b = bid;
@@ -81,7 +98,9 @@ __global__ __launch_bounds__(64 * WS * WN) void conv3d_kernel(ConvArgs a) {
   const int NF = TT + a.kt - 1;  // input frames this workgroup touches: t = tb0 - pad_t + i
   const int ncc = a.c_in / CK;
   const int S = ncc * a.kt * C::NTG;
-  const char* xclip = a.x + (long long)b * a.x_bs * ES;
+  const long long HWp = (long long)H * W;
+  // frame 0 of this clip inside the x buffer (t_alloc frames per clip, the conv's window starts at t_offset)
+  const char* xclip = a.x + (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset) * HWp) * a.ld_x * ES;
 
   f32x16 acc[TT][MT][NT];
 #pragma unroll
@@ -98,15 +117,15 @@ __global__ __launch_bounds__(64 * WS * WN) void conv3d_kernel(ConvArgs a) {
     const int t = tb0 - a.pad_t + i;
     const bool t_ok = (unsigned)t < (unsigned)a.t_in;
     char* xb = ring + ((cc * NF + i) % C::R) * C::X_BYTES;
-    const char* xsrc = xclip + ((long long)t * a.H * a.W * a.ld_x + cc * CK) * ES;
+    const char* xsrc = xclip + ((long long)t * HWp * a.ld_x + cc * CK) * ES;
 #pragma unroll
     for (int it = 0; it < (C::X_SLOTS + C::NTHREADS - 1) / C::NTHREADS; ++it) {
       const int sl = it * C::NTHREADS + tid;
       if (sl < C::X_SLOTS) {
         const int col = sl % C::HC, rowj = sl / C::HC, row = rowj % C::HR, j = rowj / C::HR;
         const int h = h0 + row - C::HALO, w = w0 + col - C::HALO;
-        const bool ok = t_ok && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
-        const char* src = ok ? xsrc + ((long long)(h * a.W + w) * a.ld_x + j * CE) * ES : a.zeros;
+        const bool ok = t_ok && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+        const char* src = ok ? xsrc + ((long long)(h * W + w) * a.ld_x + j * CE) * ES : a.zeros;
         glds16(src, xb + (sl - lane) * 16);
       }
     }
@@ -150,7 +169,8 @@ __global__ __launch_bounds__(64 * WS * WN) void conv3d_kernel(ConvArgs a) {
       for (int j = 0; j < TT; ++j)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
-          if (!skip_a) av[buf][j][i] = lds_read16(xf[j] + (((2 * st + hh) * C::HR + ws * MT + i + dh) * C::HC + r + dw) * 16);
+          if (!skip_a)
+            av[buf][j][i] = lds_read16(xf[j] + (((2 * st + hh) * C::HR + ws * MT + i + dh) * C::HC + r + dw) * 16);
     };
     load(0, 0);
 #pragma unroll
@@ -197,7 +217,7 @@ __global__ __launch_bounds__(64 * WS * WN) void conv3d_kernel(ConvArgs a) {
   float s1[NT], s2[NT];
 #pragma unroll
   for (int q = 0; q < NT; ++q) s1[q] = s2[q] = 0.f;
-  T* yclip = (T*)a.y + (long long)b * a.y_bs;
+  T* yclip = (T*)a.y + (a.lv.ypos[lvl] + (long long)b * a.t_out * HWp) * a.ld_y;
 #pragma unroll
   for (int q = 0; q < NT; ++q) {
     const int n = n0 + (wn * NT + q) * 32 + r;
@@ -213,8 +233,8 @@ __global__ __launch_bounds__(64 * WS * WN) void conv3d_kernel(ConvArgs a) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int w = w0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-            if (nok && h < a.H && w < a.W) {
-              T* dst = yclip + ((long long)(to * a.H + h) * a.W + w) * a.ld_y + n;
+            if (nok && h < H && w < W) {
+              T* dst = yclip + ((long long)(to * H + h) * W + w) * a.ld_y + n;
               float v = acc[j][i][q][e] + bias;
               if (a.accumulate) v += Elt<DT>::to_f32(*dst);
               *dst = Elt<DT>::from_f32(v);
@@ -246,7 +266,7 @@ __global__ __launch_bounds__(64 * WS * WN) void conv3d_kernel(ConvArgs a) {
         t1 += red[(((wn_ * WS + k) * NT + q) * 32 + l) * 2 + 0];
         t2 += red[(((wn_ * WS + k) * NT + q) * 32 + l) * 2 + 1];
       }
-      const long long prow = ((long long)(b * a.t_blocks + tb) * a.tiles_h + th) * a.tiles_w + tw;
+      const long long prow = a.lv.row_begin[lvl] + ((long long)(b * a.t_blocks + tb) * tiles_h + th) * tiles_w + tw;
       a.stat_part[(prow * 2 + 0) * a.c_out + n0 + tid] = t1;
       a.stat_part[(prow * 2 + 1) * a.c_out + n0 + tid] = t2;
     }
@@ -257,7 +277,8 @@ __global__ __launch_bounds__(64 * WS * WN) void conv3d_kernel(ConvArgs a) {
 struct ConvPlan {
   int family;  // 0 narrow (c_out <= 32), 1 mid (c_out == 64, 1x1), 2 wide
   int TT, NT, TH, BN;
-  int tiles_w, tiles_h, t_blocks, n_blocks, t_out;
+  int t_blocks, n_blocks, t_out;
+  ConvLevels lv;
 };
 
 static int pick_tt(int t_out, int max_tt) {
@@ -273,11 +294,15 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
   SFVOS_REQUIRE(d->c_in > 0 && d->c_in % 32 == 0 && d->c_out > 0 && d->c_out % 32 == 0,
                 "conv: channels must be positive multiples of 32 (c_in %d, c_out %d)", d->c_in, d->c_out);
   SFVOS_REQUIRE(d->c_out <= 256, "conv: c_out %d > 256 unsupported", d->c_out);
-  SFVOS_REQUIRE(d->batch >= 1 && d->t_in >= 1 && d->h >= 1 && d->w >= 1 && d->kt >= 1, "conv: bad extent");
+  SFVOS_REQUIRE(d->batch >= 1 && d->t_in >= 1 && d->kt >= 1, "conv: bad extent");
+  SFVOS_REQUIRE(d->t_offset >= 0 && d->t_alloc >= d->t_offset + d->t_in,
+                "conv: x window [t_offset %d, +t_in %d) exceeds t_alloc %d", d->t_offset, d->t_in, d->t_alloc);
   SFVOS_REQUIRE(d->pad_t >= 0 && d->pad_t < d->kt + 1, "conv: bad pad_t %d", d->pad_t);
   SFVOS_REQUIRE(d->ld_x >= d->c_in && d->ld_y >= d->c_out, "conv: pitch smaller than channel count");
   const int ce = d->dtype == SFVOS_BF16 ? 8 : 4;
   SFVOS_REQUIRE(d->ld_x % ce == 0, "conv: ld_x %d must be a multiple of %d (16-byte chunks)", d->ld_x, ce);
+  SFVOS_REQUIRE(d->pyr.n_levels >= 1 && d->pyr.n_levels <= SFVOS_MAX_LEVELS, "conv: n_levels %d out of [1,%d]",
+                d->pyr.n_levels, SFVOS_MAX_LEVELS);
   p->t_out = d->t_in + 2 * d->pad_t - d->kt + 1;
   SFVOS_REQUIRE(p->t_out >= 1, "conv: kernel longer than padded input (t_in %d, kt %d, pad_t %d)", d->t_in, d->kt,
                 d->pad_t);
@@ -290,10 +315,29 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
     p->family = 2; p->NT = d->c_out <= 192 ? 3 : 4; p->TT = pick_tt(p->t_out, p->NT == 4 ? 2 : 3); p->TH = 4;
     p->BN = 64 * p->NT;
   }
-  p->tiles_w = ceil_div(d->w, 32);
-  p->tiles_h = ceil_div(d->h, p->TH);
   p->t_blocks = ceil_div(p->t_out, p->TT);
   p->n_blocks = ceil_div(d->c_out, p->BN);
+  ConvLevels& lv = p->lv;
+  lv.n = d->pyr.n_levels;
+  long long wg = 0, rows = 0, px = 0;
+  for (int l = 0; l < SFVOS_MAX_LEVELS; ++l) {
+    const bool live = l < lv.n;
+    const int H = live ? d->pyr.h[l] : 1, W = live ? d->pyr.w[l] : 1;
+    SFVOS_REQUIRE(H >= 1 && W >= 1, "conv: level %d has bad extent %dx%d", l, H, W);
+    lv.H[l] = H; lv.W[l] = W;
+    lv.tiles_h[l] = ceil_div(H, p->TH); lv.tiles_w[l] = ceil_div(W, 32);
+    lv.wg_begin[l] = (int)wg; lv.row_begin[l] = (int)rows;
+    lv.xpos[l] = (long long)d->batch * d->t_alloc * px;
+    lv.ypos[l] = (long long)d->batch * p->t_out * px;
+    if (live) {
+      wg += (long long)d->batch * p->t_blocks * p->n_blocks * lv.tiles_h[l] * lv.tiles_w[l];
+      rows += (long long)d->batch * p->t_blocks * lv.tiles_h[l] * lv.tiles_w[l];
+      px += (long long)H * W;
+    }
+    SFVOS_REQUIRE(wg < (1ll << 31) && rows < (1ll << 31), "conv: grid out of range");
+  }
+  lv.wg_begin[SFVOS_MAX_LEVELS] = (int)wg;
+  lv.row_begin[SFVOS_MAX_LEVELS] = (int)rows;
   return SFVOS_OK;
 }
 
@@ -339,10 +383,12 @@ static int dispatch(const ConvPlan& p, const ConvArgs& a, long long grid, hipStr
 
 using namespace sfvos;
 
-extern "C" int sfvos_conv3d_stat_rows(const sfvos_conv_desc* d) {
+extern "C" int sfvos_conv3d_stat_rows(const sfvos_conv_desc* d, int* rows_per_level) {
   ConvPlan p;
   if (make_plan(d, &p) != SFVOS_OK) return SFVOS_E_ARG;
-  return d->batch * p.t_blocks * p.tiles_h * p.tiles_w;
+  if (rows_per_level)
+    for (int l = 0; l < p.lv.n; ++l) rows_per_level[l] = p.lv.row_begin[l + 1] - p.lv.row_begin[l];
+  return p.lv.row_begin[SFVOS_MAX_LEVELS];
 }
 
 extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
@@ -355,13 +401,14 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
   ConvArgs a;
   a.x = (const char*)x; a.wp = (const char*)w_packed; a.bias = bias; a.y = (char*)y; a.stat_part = stat_part;
   a.zeros = (const char*)zeros;
-  a.t_in = d->t_in; a.t_out = p.t_out; a.H = d->h; a.W = d->w; a.c_in = d->c_in; a.c_out = d->c_out; a.kt = d->kt;
+  a.batch = d->batch; a.t_in = d->t_in; a.t_alloc = d->t_alloc; a.t_offset = d->t_offset; a.t_out = p.t_out;
+  a.c_in = d->c_in; a.c_out = d->c_out; a.kt = d->kt;
   a.pad_t = d->pad_t; a.ld_x = d->ld_x; a.ld_y = d->ld_y; a.accumulate = d->accumulate;
-  a.tiles_w = p.tiles_w; a.tiles_h = p.tiles_h; a.t_blocks = p.t_blocks; a.n_blocks = p.n_blocks;
-  a.x_bs = d->x_batch_stride; a.y_bs = d->y_batch_stride;
+  a.t_blocks = p.t_blocks; a.n_blocks = p.n_blocks;
+  a.lv = p.lv;
   { const char* dbg = getenv("SFVOS_CONV_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
-  const long long grid = (long long)d->batch * p.t_blocks * p.n_blocks * p.tiles_h * p.tiles_w;
-  SFVOS_REQUIRE(grid > 0 && grid < (1ll << 31), "conv: grid %lld out of range", grid);
+  const long long grid = p.lv.wg_begin[SFVOS_MAX_LEVELS];
+  SFVOS_REQUIRE(grid > 0, "conv: empty grid");
   hipStream_t s = (hipStream_t)stream;
   if (d->dtype == SFVOS_BF16)
     return d->taps == 9 ? dispatch<SFVOS_BF16, 9>(p, a, grid, s) : dispatch<SFVOS_BF16, 1>(p, a, grid, s);

@@ -22,15 +22,23 @@
 
 namespace sfvos {
 
+struct WgradLevels {
+  int n;
+  int H[SFVOS_MAX_LEVELS], W[SFVOS_MAX_LEVELS], tiles_h[SFVOS_MAX_LEVELS], tiles_w[SFVOS_MAX_LEVELS];
+  int tile_begin[SFVOS_MAX_LEVELS + 1];  // first pixel tile of each level (tiles enumerate level, clip, th, tw)
+  long long xpos[SFVOS_MAX_LEVELS];      // first position of the level in the x / dy pyramid buffers
+  long long ypos[SFVOS_MAX_LEVELS];
+};
+
 struct WgradArgs {
   const char* x;
   const char* dy;
   float* slab;
   const char* zeros;
-  int t_in, t_out, H, W, c_in, c_out, kt, ld_x, ld_y, batch;
-  int tiles_w, tiles_h, n_blocks, c_blocks, dt_blocks, psplit;
-  long long x_bs, y_bs;
-  int ntiles;  // batch * tiles_h * tiles_w
+  int t_in, t_alloc, t_offset, t_out, c_in, c_out, kt, ld_x, ld_y, batch;
+  int n_blocks, c_blocks, dt_blocks, psplit;
+  int ntiles;  // over all levels and clips
+  WgradLevels lv;
 };
 
 template <int DT, int TAPS, int NTN, int NTC, int DG, int TH>
@@ -98,37 +106,43 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
   // stage s -> (tile, frame index fi); DMA of x[t = dt0 + fi] halo tile and dy frame fi
   auto issue = [&](int s) {
     const int tile = tile_begin + s / nfr, fi = s % nfr;
-    int k = tile;
-    const int tw = k % a.tiles_w; k /= a.tiles_w;
-    const int th = k % a.tiles_h; k /= a.tiles_h;
+    int lvl = 0;
+#pragma unroll
+    for (int l = 1; l < SFVOS_MAX_LEVELS; ++l)
+      if (l < a.lv.n && tile >= a.lv.tile_begin[l]) lvl = l;
+    const int H = a.lv.H[lvl], W = a.lv.W[lvl];
+    const long long HWp = (long long)H * W;
+    int k = tile - a.lv.tile_begin[lvl];
+    const int tw = k % a.lv.tiles_w[lvl]; k /= a.lv.tiles_w[lvl];
+    const int th = k % a.lv.tiles_h[lvl]; k /= a.lv.tiles_h[lvl];
     const int b = k;
     const int h0 = th * TH, w0 = tw * 16;
     const int t = dt0 + fi;
     char* xb = xbase + (s & 1) * C::X_BYTES;
     char* dyb = dybase + (s % C::R) * C::DY_BYTES;
     const bool dy_ok = fi < a.t_out;
-    const char* dyf = a.dy + ((long long)b * a.y_bs + (long long)fi * a.H * a.W * a.ld_y) * ES;
+    const char* dyf = a.dy + (a.lv.ypos[lvl] + ((long long)b * a.t_out + fi) * HWp) * a.ld_y * ES;
 #pragma unroll
     for (int it = 0; it < (C::DY_SLOTS + 511) / 512; ++it) {
       const int sl = it * 512 + tid;
       if (sl < C::DY_SLOTS) {
         const int j = sl % C::SPP, pos = (sl / C::SPP) % C::NPOS, tnt = sl / (C::SPP * C::NPOS);
         const int h = h0 + pos / 16, w = w0 + pos % 16, n = n_base + tnt * 32;
-        const bool ok = dy_ok && h < a.H && w < a.W && n < a.c_out;
-        const char* src = ok ? dyf + ((long long)(h * a.W + w) * a.ld_y + n + j * CE) * ES : a.zeros;
+        const bool ok = dy_ok && h < H && w < W && n < a.c_out;
+        const char* src = ok ? dyf + ((long long)(h * W + w) * a.ld_y + n + j * CE) * ES : a.zeros;
         glds16(src, dyb + (sl - lane) * 16);
       }
     }
     const bool x_ok = t < a.t_in;
-    const char* xf = a.x + ((long long)b * a.x_bs + (long long)t * a.H * a.W * a.ld_x) * ES;
+    const char* xf = a.x + (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset + t) * HWp) * a.ld_x * ES;
 #pragma unroll
     for (int it = 0; it < (C::X_SLOTS + 511) / 512; ++it) {
       const int sl = it * 512 + tid;
       if (sl < C::X_SLOTS) {
         const int j = sl % C::SPP, hp = (sl / C::SPP) % C::NHPOS, tct = sl / (C::SPP * C::NHPOS);
         const int h = h0 + hp / C::HC - C::HALO, w = w0 + hp % C::HC - C::HALO, c = c_base + tct * 32;
-        const bool ok = x_ok && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W && c < a.c_in;
-        const char* src = ok ? xf + ((long long)(h * a.W + w) * a.ld_x + c + j * CE) * ES : a.zeros;
+        const bool ok = x_ok && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W && c < a.c_in;
+        const char* src = ok ? xf + ((long long)(h * W + w) * a.ld_x + c + j * CE) * ES : a.zeros;
         glds16(src, xb + (sl - lane) * 16);
       }
     }
@@ -240,7 +254,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 struct WgradPlan {
   int cfg;  // 0: (1,2,4) 3x3 narrow-n ; 1: (2,2,2) 3x3 ; 2: (1,1,8) 3x3 c_in 32 ; 3: (2,1,4) 1x1
   int NTN, NTC, DG, TH;
-  int tiles_w, tiles_h, n_blocks, c_blocks, dt_blocks, psplit, t_out, ntiles;
+  int n_blocks, c_blocks, dt_blocks, psplit, t_out, ntiles;
+  WgradLevels lv;
 };
 
 static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
@@ -264,12 +279,31 @@ static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
     p->cfg = 1; p->NTN = 2; p->NTC = 2; p->DG = 2;
   }
   p->TH = f32 ? 4 : 8;
-  p->tiles_w = ceil_div(d->w, 16);
-  p->tiles_h = ceil_div(d->h, p->TH);
+  SFVOS_REQUIRE(d->pyr.n_levels >= 1 && d->pyr.n_levels <= SFVOS_MAX_LEVELS, "wgrad: n_levels out of range");
+  SFVOS_REQUIRE(d->batch >= 1 && d->t_offset >= 0 && d->t_alloc >= d->t_offset + d->t_in, "wgrad: bad x window");
+  WgradLevels& lv = p->lv;
+  lv.n = d->pyr.n_levels;
+  long long tiles = 0, px = 0;
+  for (int l = 0; l < SFVOS_MAX_LEVELS; ++l) {
+    const bool live = l < lv.n;
+    const int H = live ? d->pyr.h[l] : 1, W = live ? d->pyr.w[l] : 1;
+    SFVOS_REQUIRE(H >= 1 && W >= 1, "wgrad: level %d has bad extent", l);
+    lv.H[l] = H; lv.W[l] = W;
+    lv.tiles_h[l] = ceil_div(H, p->TH); lv.tiles_w[l] = ceil_div(W, 16);
+    lv.tile_begin[l] = (int)tiles;
+    lv.xpos[l] = (long long)d->batch * d->t_alloc * px;
+    lv.ypos[l] = (long long)d->batch * p->t_out * px;
+    if (live) {
+      tiles += (long long)d->batch * lv.tiles_h[l] * lv.tiles_w[l];
+      px += (long long)H * W;
+    }
+    SFVOS_REQUIRE(tiles < (1ll << 30), "wgrad: too many tiles");
+  }
+  lv.tile_begin[SFVOS_MAX_LEVELS] = (int)tiles;
   p->n_blocks = ceil_div(d->c_out, 32 * p->NTN);
   p->c_blocks = ceil_div(d->c_in, 32 * p->NTC);
   p->dt_blocks = ceil_div(d->kt, p->DG);
-  p->ntiles = d->batch * p->tiles_h * p->tiles_w;
+  p->ntiles = (int)tiles;
   const int col_blocks = p->n_blocks * p->c_blocks * p->dt_blocks;
   int ps = ceil_div(768, col_blocks);  // ~3 workgroups per CU over the launch
   if (ps > p->ntiles) ps = p->ntiles;
@@ -314,11 +348,12 @@ extern "C" int sfvos_conv3d_wgrad(const sfvos_conv_desc* d, const void* x, const
   SFVOS_REQUIRE(x && dy && grad_w && workspace && zeros, "wgrad: null pointer");
   WgradArgs a;
   a.x = (const char*)x; a.dy = (const char*)dy; a.slab = (float*)workspace; a.zeros = (const char*)zeros;
-  a.t_in = d->t_in; a.t_out = p.t_out; a.H = d->h; a.W = d->w; a.c_in = d->c_in; a.c_out = d->c_out; a.kt = d->kt;
+  a.t_in = d->t_in; a.t_alloc = d->t_alloc; a.t_offset = d->t_offset; a.t_out = p.t_out; a.c_in = d->c_in;
+  a.c_out = d->c_out; a.kt = d->kt;
   a.ld_x = d->ld_x; a.ld_y = d->ld_y; a.batch = d->batch;
-  a.tiles_w = p.tiles_w; a.tiles_h = p.tiles_h; a.n_blocks = p.n_blocks; a.c_blocks = p.c_blocks;
-  a.dt_blocks = p.dt_blocks; a.psplit = p.psplit; a.x_bs = d->x_batch_stride; a.y_bs = d->y_batch_stride;
-  a.ntiles = p.ntiles;
+  a.n_blocks = p.n_blocks; a.c_blocks = p.c_blocks;
+  a.dt_blocks = p.dt_blocks; a.psplit = p.psplit;
+  a.ntiles = p.ntiles; a.lv = p.lv;
   const long long grid = (long long)p.psplit * p.n_blocks * p.c_blocks * p.dt_blocks;
   hipStream_t s = (hipStream_t)stream;
   const bool bf = d->dtype == SFVOS_BF16;

@@ -5,8 +5,12 @@ Same constructor, `forward`, `temporally_enhance_features`, parameter names, sta
 and train/eval semantics as the reference; consumed the same way by SegmentationModel
 (model.py:184,340), OsvosSegmentationModel (osvos/osvos_model.py:28,65), train.py:74-80.
 
+All FPN levels of one temporally_enhance_features call are processed together: every conv / BN /
+weight-gradient step is ONE libsfvos launch over the whole pyramid (include/sfvos.h, "pyramid
+NDHWC"), with per-level BatchNorm statistics exactly as the reference's per-level calls produce.
+
 PyTorch is used for device memory, streams and autograd bookkeeping only: every arithmetic
-step of the path is a libsfvos call (see include/sfvos.h).  There is no CPU / eager fallback."""
+step of the path is a libsfvos call.  There is no CPU / eager fallback."""
 import ctypes
 import os
 from collections import OrderedDict
@@ -18,6 +22,9 @@ from . import _lib
 from .plan import SlowFastPlan
 
 _DT = {'fp32': (_lib.F32, torch.float32), 'bf16': (_lib.BF16, torch.bfloat16)}
+# per-level coefficient rows of a BN layer: mean, rstd, scale, shift, var_unbiased, A, B, K
+_CF_ROWS = 8
+_MEAN, _RSTD, _SCALE, _SHIFT, _VARU, _CA, _CB, _CK = range(8)
 
 
 def _ptr(t, elem_offset=0):
@@ -76,9 +83,38 @@ class _NullRegion(object):
 _NULL = _NullRegion()
 
 
-class _LevelState(object):
-    """What one forward of one pyramid level leaves behind for its backward."""
-    __slots__ = ('B', 'H', 'W', 'bufs', 'coef', 'train', 'dtype_name')
+class PackedClip(object):
+    """Channels-last clips of a whole pyramid in the layout the kernels consume (a
+    producer that emits NHWC frames hands them over without any layout pass).
+
+    data : [B * frames * sum_l(H_l*W_l), C] tensor in the compute dtype, level-major
+           (position(l,b,t,h,w) as in include/sfvos.h)
+    """
+
+    def __init__(self, data, shapes, batch, frames, keys=None):
+        self.data, self.shapes, self.batch, self.frames = data, [tuple(s) for s in shapes], batch, frames
+        self.keys = list(keys) if keys is not None else [str(i) for i in range(len(shapes))]
+        pix = sum(h * w for h, w in self.shapes)
+        if data.dim() != 2 or data.shape[0] != batch * frames * pix:
+            raise ValueError('PackedClip: data must be [B*frames*sum(H*W), C] = [%d, C], got %s'
+                             % (batch * frames * pix, tuple(data.shape)))
+
+    @staticmethod
+    def from_levels(levels, keys=None):
+        """levels: list of [B,T,H,W,C] tensors (one per FPN level) -> PackedClip (copies once)."""
+        B, T = levels[0].shape[0], levels[0].shape[1]
+        shapes = [tuple(x.shape[2:4]) for x in levels]
+        data = torch.cat([x.reshape(-1, x.shape[-1]) for x in levels], 0)
+        return PackedClip(data, shapes, B, T, keys)
+
+
+class _State(object):
+    """What one forward leaves behind for its backward."""
+    __slots__ = ('B', 'shapes', 'bufs', 'coef', 'train', 'dtype_name', 'slow_offset')
+
+
+def _lv_total(lv):
+    return sum(lv.m[i] for i in range(lv.n_levels))
 
 
 class SlowFastLayers(nn.Module):
@@ -113,10 +149,10 @@ class SlowFastLayers(nn.Module):
         self._timer = KernelTimer()
         return self._timer
 
-    def _t(self, kind, layer, H, W):
+    def _t(self, kind, layer):
         if self._timer is None:
             return _NULL
-        return self._timer.region('%s/%s/%dx%d' % (kind, layer, H, W))
+        return self._timer.region('%s/%s' % (kind, layer))
 
     # ------------------------------------------------------------------ helpers
     def _check_ready(self, ref):
@@ -150,144 +186,148 @@ class SlowFastLayers(nn.Module):
         self._packs[key] = (tag, packed)
         return packed
 
-    def _desc(self, layer, B, H, W, dt_id, ld_x, ld_y, dgrad=False, accumulate=0):
+    def _desc(self, layer, B, pyr, dt_id, ld_x, ld_y, t_alloc=None, t_offset=0, dgrad=False, accumulate=0):
         d = _lib.ConvDesc()
-        d.dtype, d.batch, d.h, d.w, d.kt, d.taps = dt_id, B, H, W, layer.kt, layer.taps
+        d.dtype, d.batch, d.kt, d.taps, d.pyr = dt_id, B, layer.kt, layer.taps, pyr
         if dgrad:  # conv over dy producing dx: channels swapped, full temporal padding
             d.t_in, d.c_in, d.c_out, d.pad_t = layer.t_out, layer.c_out, layer.c_in, layer.kt - 1
-            d.x_batch_stride = layer.t_out * H * W * ld_x
-            d.y_batch_stride = layer.t_in * H * W * ld_y
+            d.t_alloc, d.t_offset = layer.t_out, 0
         else:
             d.t_in, d.c_in, d.c_out, d.pad_t = layer.t_in, layer.c_in, layer.c_out, 0
-            d.x_batch_stride = layer.t_in * H * W * ld_x
-            d.y_batch_stride = layer.t_out * H * W * ld_y
+            d.t_alloc, d.t_offset = (layer.t_in if t_alloc is None else t_alloc), t_offset
         d.ld_x, d.ld_y, d.accumulate = ld_x, ld_y, accumulate
         return d
 
-    # ------------------------------------------------------------------ forward engine (one level)
-    def _engine_forward(self, slow, fast, ndhwc_input, keep):
-        """slow/fast: [B,C,T,H,W] fp32 (any strides) or, with ndhwc_input, [B,T,H,W,C] in the
-        compute dtype.  Returns (merged [B,256,H,W] fp32, state or None)."""
+    def _src_window(self, layer, slow_offset):
+        """(buffer name, t_alloc, t_offset) of a layer's input: the slow pathway's first conv reads its
+        centre frames straight out of the fast clip when the caller's slow tensor aliases it."""
+        if layer.src == 'xs0' and slow_offset is not None:
+            return 'xf0', self.plan.fp, slow_offset
+        return layer.src, None, 0
+
+    # ------------------------------------------------------------------ forward engine (whole pyramid)
+    def _engine_forward(self, shapes, B, xf0, xs0, slow_offset, keep):
+        """xf0 / xs0: flat pyramid buffers [B*T*sum(HW), C] in the compute dtype (xs0 None when the slow
+        clip aliases frames [slow_offset, slow_offset+sp) of the fast clip).
+        Returns (list of merged [B,256,H,W] fp32 per level, state or None)."""
         plan = self.plan
         dt_name = self.precision
         dt_id, tdt = _DT[dt_name]
-        dev = fast.device
+        dev = xf0.device
         st = _stream()
         zeros = self._zero_page(dev)
-        if ndhwc_input:
-            B, Tf, H, W, C = fast.shape
-            Ts = slow.shape[1]
-        else:
-            B, C, Tf, H, W = fast.shape
-            Ts = slow.shape[2]
-        if C != plan.input_size or Ts != plan.sp or Tf != plan.fp:
-            raise RuntimeError('expected %d channels and %d/%d slow/fast frames, got C=%d, %d/%d'
-                               % (plan.input_size, plan.sp, plan.fp, C, Ts, Tf))
-        if slow.shape[0] != B or tuple(slow.shape[-2:] if not ndhwc_input else slow.shape[2:4]) != (H, W):
-            raise RuntimeError('slow and fast inputs disagree in batch or spatial size')
-        bufs = {}
+        L = len(shapes)
+        pix = sum(h * w for h, w in shapes)
+        pyr = _lib.make_pyramid(shapes)
+        bufs = {'xf0': xf0}
+        if xs0 is not None:
+            bufs['xs0'] = xs0
 
         def alloc(name):
             b = plan.buffers[name]
-            bufs[name] = torch.empty((B, b.frames, H, W, b.channels), dtype=tdt, device=dev)
+            bufs[name] = torch.empty((B * b.frames * pix, b.channels), dtype=tdt, device=dev)
             return bufs[name]
-
-        # -- layout: frames (NCHW stacks viewed as NCDHW, model.py:157-158) -> NDHWC
-        for name, src in (('xs0', slow), ('xf0', fast)):
-            if ndhwc_input:
-                if src.dtype != tdt or not src.is_contiguous():
-                    raise RuntimeError('NDHWC inputs must be contiguous %s' % tdt)
-                bufs[name] = src
-            else:
-                s = src if src.dtype == torch.float32 else src.float()
-                dst = alloc(name)
-                T = s.shape[2]
-                for b in range(B):
-                    _lib.call('sfvos_frames_to_ndhwc', _ptr(s[b]), s.stride(2), s.stride(1), s.stride(3), s.stride(4),
-                              _ptr(dst[b]), dt_id, T, C, H, W, C, st)
 
         train = self.training
         coef = {}
+        lib = _lib.load()
         for l in plan.layers:
             conv, bn = getattr(self, l.conv), getattr(self, l.bn)
-            src = bufs[l.src]
+            sname, t_alloc, t_off = self._src_window(l, slow_offset)
+            src = bufs[sname]
             raw = alloc(l.raw)
             if l.dst not in bufs:
                 alloc(l.dst)
             dst = bufs[l.dst]
-            d = self._desc(l, B, H, W, dt_id, src.shape[-1], l.c_out)
-            M = B * l.t_out * H * W
+            d = self._desc(l, B, pyr, dt_id, src.shape[-1], l.c_out, t_alloc, t_off)
+            lv = _lib.make_levels(shapes, B, l.t_out)
             wp = self._packed(l, 'fwd', dt_name)
             bias = _ptr(conv.bias.detach()) if conv.bias is not None else None
-            cf = torch.empty((6, l.c_out), dtype=torch.float32, device=dev)  # mean rstd scale shift var_unb spare
+            cf = torch.empty((L, _CF_ROWS, l.c_out), dtype=torch.float32, device=dev)
+            cs = _CF_ROWS * l.c_out
             if train:
-                if M <= 1:
+                if min(lv.m[i] for i in range(L)) <= 1:
                     raise ValueError('Expected more than 1 value per channel when training, got input size %s'
-                                     % str([B, l.c_out, l.t_out, H, W]))
-                rows = _lib.load().sfvos_conv3d_stat_rows(ctypes.byref(d))
+                                     % str([B, l.c_out, l.t_out] + list(shapes[-1])))
+                rows_pl = (ctypes.c_int * _lib.MAX_LEVELS)()
+                rows = lib.sfvos_conv3d_stat_rows(ctypes.byref(d), rows_pl)
                 if rows <= 0:
                     _lib.check(rows if rows < 0 else -1, 'sfvos_conv3d_stat_rows')
                 part = torch.empty((rows, 2, l.c_out), dtype=torch.float32, device=dev)
-                with self._t('conv_fwd', l.name, H, W):
+                with self._t('conv_fwd', l.name):
                     _lib.call('sfvos_conv3d', ctypes.byref(d), _ptr(src), _ptr(wp), bias, _ptr(raw), _ptr(part),
                               _ptr(zeros), st)
-                _lib.call('sfvos_bn_finalize', _ptr(part), rows, M, _ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
-                          float(bn.eps), l.c_out, _ptr(cf[0]), _ptr(cf[1]), _ptr(cf[2]), _ptr(cf[3]), _ptr(cf[4]), st)
+                _lib.call('sfvos_bn_finalize', _ptr(part), L, rows_pl, lv.m, _ptr(bn.weight.detach()),
+                          _ptr(bn.bias.detach()), float(bn.eps), l.c_out, _ptr(cf[0, _MEAN]), _ptr(cf[0, _RSTD]),
+                          _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), _ptr(cf[0, _VARU]), cs, st)
                 if bn.track_running_stats and bn.running_mean is not None:
-                    bn.num_batches_tracked.add_(1)
+                    # the reference runs the levels one after another: L consecutive momentum updates
+                    bn.num_batches_tracked.add_(L)
                     if bn.momentum is None:
                         raise RuntimeError('BatchNorm momentum=None (cumulative average) is not supported')
-                    _lib.call('sfvos_bn_running_update', _ptr(bn.running_mean), _ptr(bn.running_var), _ptr(cf[0]),
-                              _ptr(cf[4]), 1, l.c_out, float(bn.momentum), st)
+                    _lib.call('sfvos_bn_running_update', _ptr(bn.running_mean), _ptr(bn.running_var),
+                              _ptr(cf[0, _MEAN]), _ptr(cf[0, _VARU]), L, cs, l.c_out, float(bn.momentum), st)
             else:
-                with self._t('conv_fwd', l.name, H, W):
+                with self._t('conv_fwd', l.name):
                     _lib.call('sfvos_conv3d', ctypes.byref(d), _ptr(src), _ptr(wp), bias, _ptr(raw), None, _ptr(zeros),
                               st)
                 _lib.call('sfvos_bn_eval_coeffs', _ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
-                          _ptr(bn.running_mean), _ptr(bn.running_var), float(bn.eps), l.c_out, _ptr(cf[2]),
-                          _ptr(cf[3]), st)
-                if keep:  # eval-mode backward needs (running_mean, rstd of running_var)
-                    cf[0].copy_(bn.running_mean)
-                    cf[1].copy_(torch.rsqrt(bn.running_var + bn.eps))
-            with self._t('bn_apply', l.name, H, W):
-                _lib.call('sfvos_bn_apply', _ptr(raw), l.c_out, _ptr(dst, l.dst_off), dst.shape[-1], dt_id, M, l.c_out,
-                          _ptr(cf[2]), _ptr(cf[3]), 1 if l.relu else 0, st)
+                          _ptr(bn.running_mean), _ptr(bn.running_var), float(bn.eps), l.c_out, _ptr(cf[0, _MEAN]),
+                          _ptr(cf[0, _RSTD]), _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), st)
+                if L > 1:
+                    cf[1:, :4] = cf[0, :4]  # same running statistics for every level (plumbing copy)
+            with self._t('bn_apply', l.name):
+                _lib.call('sfvos_bn_apply', _ptr(raw), l.c_out, _ptr(dst, l.dst_off), dst.shape[-1], dt_id,
+                          ctypes.byref(lv), l.c_out, _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), cs,
+                          1 if l.relu else 0, st)
             coef[l.name] = cf
 
-        # -- cat([slow224, fast32], 1).squeeze(2) (model.py:162) as the caller's NCHW fp32 tensor
-        merged = torch.empty((B, 256, H, W), dtype=torch.float32, device=dev)
-        _lib.call('sfvos_ndhwc_to_frames', _ptr(bufs['out']), dt_id, _ptr(merged), 256 * H * W, H * W, W, 1, B, 256,
-                  H, W, 256, 0, st)
+        # -- cat([slow224, fast32], 1).squeeze(2) (model.py:162) as the caller's NCHW fp32 tensors
+        merged = []
+        off = 0
+        out = bufs['out']
+        for (H, W) in shapes:
+            m = torch.empty((B, 256, H, W), dtype=torch.float32, device=dev)
+            _lib.call('sfvos_ndhwc_to_frames', _ptr(out, off * 256), dt_id, _ptr(m), 256 * H * W, H * W, W, 1, B, 256,
+                      H, W, 256, 0, st)
+            off += B * H * W
+            merged.append(m)
         if not keep:
             return merged, None
-        state = _LevelState()
-        state.B, state.H, state.W, state.bufs, state.coef = B, H, W, bufs, coef
-        state.train, state.dtype_name = train, dt_name
+        state = _State()
+        state.B, state.shapes, state.bufs, state.coef = B, shapes, bufs, coef
+        state.train, state.dtype_name, state.slow_offset = train, dt_name, slow_offset
         del bufs['out']
         return merged, state
 
-    # ------------------------------------------------------------------ backward engine (one level)
+    # ------------------------------------------------------------------ backward engine (whole pyramid)
     def _engine_backward(self, state, g_merged, need_slow, need_fast, need_param):
         plan = self.plan
         dt_name = state.dtype_name
         dt_id, tdt = _DT[dt_name]
-        B, H, W, bufs, coef = state.B, state.H, state.W, state.bufs, state.coef
-        dev = g_merged.device
+        B, shapes, bufs, coef = state.B, state.shapes, state.bufs, state.coef
+        dev = bufs['xf0'].device
         st = _stream()
         zeros = self._zero_page(dev)
         lib = _lib.load()
-        g = g_merged if (g_merged.dtype == torch.float32 and g_merged.is_contiguous()) else g_merged.float().contiguous()
-
+        pix = sum(h * w for h, w in shapes)
+        pyr = _lib.make_pyramid(shapes)
         gb = {}  # gradient buffers w.r.t. activation buffers
 
-        def galloc(name):
+        def galloc(name, zero=False):
             b = plan.buffers[name]
-            gb[name] = torch.empty((B, b.frames, H, W, b.channels), dtype=tdt, device=dev)
+            fn = torch.zeros if zero else torch.empty
+            gb[name] = fn((B * b.frames * pix, b.channels), dtype=tdt, device=dev)
             return gb[name]
 
-        galloc('out')
-        _lib.call('sfvos_frames_to_ndhwc', _ptr(g), 256 * H * W, H * W, W, 1, _ptr(gb['out']), dt_id, B, 256, H, W,
-                  256, st)
+        galloc('out', zero=any(g is None for g in g_merged))
+        off = 0
+        for (H, W), g in zip(shapes, g_merged):
+            if g is not None:
+                g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
+                _lib.call('sfvos_frames_to_ndhwc', _ptr(g), 256 * H * W, H * W, W, 1, _ptr(gb['out'], off * 256),
+                          dt_id, B, 256, H, W, 256, st)
+            off += B * H * W
         grads = {}
         written = set()
         any_param = any(need_param.values())
@@ -302,42 +342,45 @@ class SlowFastLayers(nn.Module):
                 continue
             if not first and not (any_param or need_slow or need_fast):
                 continue
-            M = B * l.t_out * H * W
+            lv = _lib.make_levels(shapes, B, l.t_out)
             cf = coef[l.name]
+            cs = _CF_ROWS * l.c_out
             dy = gb[l.dst]
             raw = bufs[l.raw]
-            rows = lib.sfvos_bn_bwd_rows(M)
+            rows = lib.sfvos_bn_bwd_rows(ctypes.byref(lv))
             part = torch.empty((rows, 2, l.c_out), dtype=torch.float32, device=dev)
-            treg = self._t('bn_bwd', l.name, H, W)
+            treg = self._t('bn_bwd', l.name)
             treg.__enter__()
-            _lib.call('sfvos_bn_bwd_reduce', _ptr(dy, l.dst_off), dy.shape[-1], _ptr(raw), l.c_out, dt_id, M, l.c_out,
-                      _ptr(cf[2]), _ptr(cf[3]), _ptr(cf[0]), _ptr(cf[1]), 1 if l.relu else 0, _ptr(part), st)
+            _lib.call('sfvos_bn_bwd_reduce', _ptr(dy, l.dst_off), dy.shape[-1], _ptr(raw), l.c_out, dt_id,
+                      ctypes.byref(lv), l.c_out, _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), _ptr(cf[0, _MEAN]),
+                      _ptr(cf[0, _RSTD]), cs, 1 if l.relu else 0, _ptr(part), st)
             dgamma = torch.empty(l.c_out, dtype=torch.float32, device=dev)
             dbeta = torch.empty(l.c_out, dtype=torch.float32, device=dev)
-            abk = torch.empty((3, l.c_out), dtype=torch.float32, device=dev)
-            _lib.call('sfvos_bn_bwd_finalize', _ptr(part), rows, M, _ptr(bn.weight.detach()), _ptr(cf[0]), _ptr(cf[1]),
-                      l.c_out, 1 if state.train else 0, 0, _ptr(dgamma), _ptr(dbeta), _ptr(abk[0]), _ptr(abk[1]),
-                      _ptr(abk[2]), st)
+            _lib.call('sfvos_bn_bwd_finalize', _ptr(part), ctypes.byref(lv), _ptr(bn.weight.detach()),
+                      _ptr(cf[0, _MEAN]), _ptr(cf[0, _RSTD]), cs, l.c_out, 1 if state.train else 0, 0, _ptr(dgamma),
+                      _ptr(dbeta), _ptr(cf[0, _CA]), _ptr(cf[0, _CB]), _ptr(cf[0, _CK]), st)
             grads[l.bn + '.weight'], grads[l.bn + '.bias'] = dgamma, dbeta
-            dx = torch.empty((B, l.t_out, H, W, l.c_out), dtype=tdt, device=dev)
+            dx = torch.empty((_lv_total(lv), l.c_out), dtype=tdt, device=dev)
             bpart = torch.empty((rows, l.c_out), dtype=torch.float32, device=dev) if need_b else None
             _lib.call('sfvos_bn_bwd_apply', _ptr(dy, l.dst_off), dy.shape[-1], _ptr(raw), l.c_out, _ptr(dx), l.c_out,
-                      dt_id, M, l.c_out, _ptr(cf[2]), _ptr(cf[3]), 1 if l.relu else 0, _ptr(abk[0]), _ptr(abk[1]),
-                      _ptr(abk[2]), _ptr(bpart) if need_b else None, st)
+                      dt_id, ctypes.byref(lv), l.c_out, _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), cs,
+                      1 if l.relu else 0, _ptr(cf[0, _CA]), _ptr(cf[0, _CB]), _ptr(cf[0, _CK]),
+                      _ptr(bpart) if need_b else None, st)
             treg.__exit__(None, None, None)
             if need_b:
                 db = torch.empty(l.c_out, dtype=torch.float32, device=dev)
                 _lib.call('sfvos_reduce_rows', _ptr(bpart), rows, l.c_out, _ptr(db), 0, st)
                 grads[l.conv + '.bias'] = db
-            src = bufs[l.src]
+            sname, t_alloc, t_off = self._src_window(l, state.slow_offset)
+            src = bufs[sname]
             if need_w:
-                d = self._desc(l, B, H, W, dt_id, src.shape[-1], l.c_out)
+                d = self._desc(l, B, pyr, dt_id, src.shape[-1], l.c_out, t_alloc, t_off)
                 nbytes = lib.sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
                 if nbytes == 0:
                     _lib.check(-1, 'sfvos_conv3d_wgrad_workspace_bytes')
                 ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
                 gw = torch.empty(conv.weight.shape, dtype=torch.float32, device=dev)
-                with self._t('wgrad', l.name, H, W):
+                with self._t('wgrad', l.name):
                     _lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), _ptr(src), _ptr(dx), _ptr(gw), 0, _ptr(ws),
                               _ptr(zeros), st)
                 grads[l.conv + '.weight'] = gw
@@ -346,91 +389,189 @@ class SlowFastLayers(nn.Module):
                     galloc(l.src)
                 gsrc = gb[l.src]
                 acc = 1 if l.src in written else 0
-                d = self._desc(l, B, H, W, dt_id, l.c_out, gsrc.shape[-1], dgrad=True, accumulate=acc)
+                d = self._desc(l, B, pyr, dt_id, l.c_out, gsrc.shape[-1], dgrad=True, accumulate=acc)
                 wp = self._packed(l, 'dgrad', dt_name)
-                with self._t('conv_dgrad', l.name, H, W):
+                with self._t('conv_dgrad', l.name):
                     _lib.call('sfvos_conv3d', ctypes.byref(d), _ptr(dx), _ptr(wp), None, _ptr(gsrc), None, _ptr(zeros),
                               st)
                 written.add(l.src)
             del dx
         return grads, gb
 
+    # ------------------------------------------------------------------ input layout
+    def _to_pyramid(self, tensors, frames, dt_id, tdt):
+        """list over levels of [B,C,T,H,W] fp32 (any strides) -> flat pyramid buffer (model.py:157-158)."""
+        B, C = tensors[0].shape[0], tensors[0].shape[1]
+        pix = sum(t.shape[3] * t.shape[4] for t in tensors)
+        flat = torch.empty((B * frames * pix, C), dtype=tdt, device=tensors[0].device)
+        st = _stream()
+        off = 0
+        for t in tensors:
+            s = t if t.dtype == torch.float32 else t.float()
+            H, W = s.shape[3], s.shape[4]
+            for b in range(B):
+                _lib.call('sfvos_frames_to_ndhwc', _ptr(s[b]), s.stride(2), s.stride(1), s.stride(3), s.stride(4),
+                          _ptr(flat, (off + b * frames * H * W) * C), dt_id, frames, C, H, W, C, st)
+            off += B * frames * H * W
+        return flat
+
+    def _slow_alias_offset(self, slow_list, fast_list):
+        """k if every slow[l] is exactly frames [k, k+sp) of fast[l] (same storage and strides -- what
+        SegmentationModel passes, model.py:336-338), else None."""
+        k_all = None
+        for s, f in zip(slow_list, fast_list):
+            if s.dtype != f.dtype or s.stride() != f.stride() or s.shape[:2] != f.shape[:2] \
+                    or s.shape[3:] != f.shape[3:]:
+                return None
+            if s.untyped_storage().data_ptr() != f.untyped_storage().data_ptr() or f.stride(2) == 0:
+                return None
+            delta = s.storage_offset() - f.storage_offset()
+            if delta < 0 or delta % f.stride(2) != 0:
+                return None
+            k = delta // f.stride(2)
+            if k + s.shape[2] > f.shape[2] or (k_all is not None and k != k_all):
+                return None
+            k_all = k
+        return k_all
+
     # ------------------------------------------------------------------ reference API
-    def _run_level(self, slow, fast, ndhwc_input=False):
-        self._check_ready(fast)
+    def _run(self, slow_list, fast_list):
+        """lists (one entry per FPN level) of [B,C,T,H,W] tensors -> list of merged [B,256,H,W]."""
+        self._check_ready(fast_list[0])
+        plan = self.plan
+        f0, s0 = fast_list[0], slow_list[0]
+        if f0.shape[1] != plan.input_size or s0.shape[2] != plan.sp or f0.shape[2] != plan.fp:
+            raise RuntimeError('expected %d channels and %d/%d slow/fast frames, got C=%d, %d/%d'
+                               % (plan.input_size, plan.sp, plan.fp, f0.shape[1], s0.shape[2], f0.shape[2]))
+        for s, f in zip(slow_list, fast_list):
+            if s.shape[0] != f.shape[0] or s.shape[3:] != f.shape[3:] or f.shape[0] != f0.shape[0]:
+                raise RuntimeError('slow and fast inputs disagree in batch or spatial size')
+        if len(fast_list) > _lib.MAX_LEVELS:
+            raise RuntimeError('at most %d pyramid levels per call, got %d' % (_lib.MAX_LEVELS, len(fast_list)))
         names = [n for n, _ in self.named_parameters()]
         params = [p for _, p in self.named_parameters()]
-        # decided here: inside Function.forward grad mode is always off
-        keep = torch.is_grad_enabled() and (slow.requires_grad or fast.requires_grad
+        keep = torch.is_grad_enabled() and (any(t.requires_grad for t in list(slow_list) + list(fast_list))
                                             or any(p.requires_grad for p in params))
-        return _SlowFastLevelFn.apply(self, (ndhwc_input, keep), names, slow, fast, *params)
+        meta = dict(mode='frames', L=len(fast_list), keep=keep)
+        return _SlowFastPyramidFn.apply(self, meta, names, *(list(slow_list) + list(fast_list) + params))
 
     def forward(self, slow, fast):
         """(slow [B,C,Ts,H,W], fast [B,C,Tf,H,W]) -> (slow [B,224,1,H,W], fast [B,32,1,H,W]) -- model.py:118-149."""
-        merged = self._run_level(slow, fast)
+        merged = self._run([slow], [fast])[0]
         return merged[:, :224].unsqueeze(2), merged[:, 224:].unsqueeze(2)
 
     def temporally_enhance_features(self, slow_features, fast_features):
         """list(len B) of OrderedDict level -> [T,C,H,W]  ->  OrderedDict level -> [B,256,H,W] (model.py:151-165)."""
         slow_features = {k: [dic[k] for dic in slow_features] for k in slow_features[0]}
         fast_features = {k: [dic[k] for dic in fast_features] for k in fast_features[0]}
-        merged_features = OrderedDict()
-        for key in slow_features.keys():
-            s = torch.stack(slow_features[key]).to(self.device).transpose(1, 2)
-            f = torch.stack(fast_features[key]).to(self.device).transpose(1, 2)
-            merged_features[key] = self._run_level(s, f)
-        return merged_features
+        keys = list(slow_features.keys())
+        slow_list = [torch.stack(slow_features[k]).to(self.device).transpose(1, 2) for k in keys]
+        fast_list = [torch.stack(fast_features[k]).to(self.device).transpose(1, 2) for k in keys]
+        merged = self._run(slow_list, fast_list)
+        return OrderedDict(zip(keys, merged))
 
-    def temporally_enhance_features_ndhwc(self, slow_features, fast_features):
-        """Same as temporally_enhance_features for producers that already hold channels-last clips:
-        OrderedDict level -> [B,T,H,W,C] tensors in the compute dtype; skips the
-        stack/transpose layout pass."""
-        merged = OrderedDict()
-        for key in slow_features.keys():
-            merged[key] = self._run_level(slow_features[key], fast_features[key], ndhwc_input=True)
-        return merged
+    def enhance_packed(self, clip, slow_offset=None):
+        """PackedClip of the FAST window (channels-last, compute dtype) -> OrderedDict level -> [B,256,H,W].
+        The slow pathway reads frames [slow_offset, slow_offset+sp) of the same clip; default = the
+        centre frames, as SegmentationModel._slice_features takes them (model.py:242-248,322,337)."""
+        self._check_ready(clip.data)
+        plan = self.plan
+        _, tdt = _DT[self.precision]
+        if clip.frames != plan.fp or clip.data.shape[1] != plan.input_size or clip.data.dtype != tdt \
+                or not clip.data.is_contiguous():
+            raise RuntimeError('PackedClip must hold %d frames x %d channels, contiguous %s'
+                               % (plan.fp, plan.input_size, tdt))
+        if len(clip.shapes) > _lib.MAX_LEVELS:
+            raise RuntimeError('at most %d pyramid levels per call' % _lib.MAX_LEVELS)
+        if slow_offset is None:
+            slow_offset = plan.fp // 2 - plan.sp // 2
+        if slow_offset < 0 or slow_offset + plan.sp > plan.fp:
+            raise RuntimeError('slow window [%d, %d) outside the fast clip' % (slow_offset, slow_offset + plan.sp))
+        names = [n for n, _ in self.named_parameters()]
+        params = [p for _, p in self.named_parameters()]
+        keep = torch.is_grad_enabled() and (clip.data.requires_grad or any(p.requires_grad for p in params))
+        meta = dict(mode='packed', L=len(clip.shapes), keep=keep, shapes=clip.shapes, B=clip.batch,
+                    slow_offset=slow_offset)
+        merged = _SlowFastPyramidFn.apply(self, meta, names, clip.data, *params)
+        return OrderedDict(zip(clip.keys, merged))
 
 
-class _SlowFastLevelFn(torch.autograd.Function):
+class _SlowFastPyramidFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module, flags, names, slow, fast, *params):
-        ndhwc_input, keep = flags
-        merged, state = module._engine_forward(slow.detach(), fast.detach(), ndhwc_input, keep)
-        ctx.module, ctx.state, ctx.names, ctx.ndhwc_input = module, state, names, ndhwc_input
-        ctx.in_meta = (slow.shape, slow.dtype, fast.shape, fast.dtype)
-        return merged
+    def forward(ctx, module, meta, names, *tensors):
+        L, keep = meta['L'], meta['keep']
+        dt_id, tdt = _DT[module.precision]
+        if meta['mode'] == 'frames':
+            slow_list = [t.detach() for t in tensors[:L]]
+            fast_list = [t.detach() for t in tensors[L:2 * L]]
+            n_in = 2 * L
+            B = fast_list[0].shape[0]
+            shapes = [tuple(f.shape[3:]) for f in fast_list]
+            slow_offset = module._slow_alias_offset(slow_list, fast_list)
+            xf0 = module._to_pyramid(fast_list, module.plan.fp, dt_id, tdt)
+            xs0 = None if slow_offset is not None else module._to_pyramid(slow_list, module.plan.sp, dt_id, tdt)
+            ctx.in_meta = [(t.shape, t.dtype) for t in tensors[:n_in]]
+        else:
+            n_in = 1
+            B, shapes, slow_offset = meta['B'], meta['shapes'], meta['slow_offset']
+            xf0, xs0 = tensors[0].detach(), None
+        merged, state = module._engine_forward(shapes, B, xf0, xs0, slow_offset, keep)
+        ctx.module, ctx.state, ctx.names, ctx.mode, ctx.n_in, ctx.L = module, state, names, meta['mode'], n_in, L
+        return tuple(merged)
 
     @staticmethod
-    def backward(ctx, g_merged):
-        module, state, names = ctx.module, ctx.state, ctx.names
+    def backward(ctx, *g_merged):
+        module, state, names, L = ctx.module, ctx.state, ctx.names, ctx.L
         if state is None:
             raise RuntimeError('backward through a forward that ran without grad state')
-        need_slow, need_fast = ctx.needs_input_grad[3], ctx.needs_input_grad[4]
-        need_param = {n: bool(ctx.needs_input_grad[5 + i]) for i, n in enumerate(names)}
-        grads, gb = module._engine_backward(state, g_merged, need_slow, need_fast, need_param)
+        nig = ctx.needs_input_grad
+        base = 3
+        if ctx.mode == 'frames':
+            need_slow = any(nig[base + i] for i in range(L))
+            need_fast = any(nig[base + L + i] for i in range(L))
+        else:
+            need_slow = need_fast = bool(nig[base])
+        need_param = {n: bool(nig[base + ctx.n_in + i]) for i, n in enumerate(names)}
+        grads, gb = module._engine_backward(state, list(g_merged), need_slow, need_fast, need_param)
         ctx.state = None
-        g_slow = g_fast = None
         dt_id, _ = _DT[state.dtype_name]
         st = _stream()
-        for which, key in ((0, 'xs0'), (1, 'xf0')):
-            if not (need_slow, need_fast)[which]:
-                continue
-            shape, dtype = ctx.in_meta[2 * which], ctx.in_meta[2 * which + 1]
-            gbuf = gb[key]
-            if ctx.ndhwc_input:
-                gi = gbuf.to(dtype)
-            else:
-                B, C, T, H, W = shape
-                gi = torch.empty(shape, dtype=torch.float32, device=gbuf.device)
-                for b in range(B):
-                    _lib.call('sfvos_ndhwc_to_frames', _ptr(gbuf[b]), dt_id, _ptr(gi[b]), gi.stride(2), gi.stride(1),
-                              gi.stride(3), gi.stride(4), T, C, H, W, C, 0, st)
-                gi = gi.to(dtype)
-            if which == 0:
-                g_slow = gi
-            else:
-                g_fast = gi
-        out = [None, None, None, g_slow, g_fast]
-        for i, n in enumerate(names):
+        B, shapes = state.B, state.shapes
+        out = [None, None, None]
+        if ctx.mode == 'frames':
+            g_in = [None] * (2 * L)
+            for which, key, frames in ((0, 'xs0', module.plan.sp), (1, 'xf0', module.plan.fp)):
+                if not (need_slow, need_fast)[which]:
+                    continue
+                gbuf = gb[key]
+                C = gbuf.shape[-1]
+                off = 0
+                for i, (H, W) in enumerate(shapes):
+                    shape, dtype = ctx.in_meta[which * L + i]
+                    if nig[base + which * L + i]:
+                        gi = torch.empty(shape, dtype=torch.float32, device=gbuf.device)
+                        for b in range(B):
+                            _lib.call('sfvos_ndhwc_to_frames', _ptr(gbuf, (off + b * frames * H * W) * C), dt_id,
+                                      _ptr(gi[b]), gi.stride(2), gi.stride(1), gi.stride(3), gi.stride(4), frames, C,
+                                      H, W, C, 0, st)
+                        g_in[which * L + i] = gi.to(dtype)
+                    off += B * frames * H * W
+            out.extend(g_in)
+        else:
+            g = None
+            if need_fast:
+                g = gb['xf0'].clone()
+                gs = gb['xs0']  # slow window gradient, added into its frames of the fast clip (plumbing adds)
+                sp, fp, so = module.plan.sp, module.plan.fp, state.slow_offset
+                off_f = off_s = 0
+                for (H, W) in shapes:
+                    P = H * W
+                    vf = g[off_f: off_f + B * fp * P].view(B, fp, P, -1)
+                    vs = gs[off_s: off_s + B * sp * P].view(B, sp, P, -1)
+                    vf[:, so: so + sp] += vs
+                    off_f += B * fp * P
+                    off_s += B * sp * P
+            out.append(g)
+        for n in names:
             out.append(grads.get(n) if need_param[n] else None)
         return tuple(out)

@@ -1,7 +1,7 @@
 """GPU: every libsfvos kernel, called through the C ABI (ctypes), against a plain PyTorch fp32
-reference of the same op computed on the CPU.  Tolerances: fp32 path 1e-4 relative to the
-tensor scale (exact-f32 MFMA, only summation order differs); bf16 path 2e-2 (bf16 operands,
-f32 accumulate) -- stated per assert."""
+reference of the same op computed on the CPU.  Pyramids of 1-3 levels exercise the grouped
+launches.  Tolerances: fp32 path 1e-4 relative to the tensor scale (exact-f32 MFMA, only summation
+order differs); bf16 path 2e-2 (bf16 operands, f32 accumulate) -- stated per assert."""
 import ctypes
 
 import numpy as np
@@ -36,133 +36,183 @@ def relmax(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-def make_desc(_lib, prec, B, T, H, W, cin, cout, kt, taps, pad_t, ld_x, ld_y, acc=0):
+def make_desc(_lib, prec, B, T, shapes, cin, cout, kt, taps, pad_t, ld_x, ld_y, acc=0, t_alloc=None, t_offset=0):
     d = _lib.ConvDesc()
     d.dtype = _lib.F32 if prec == 'fp32' else _lib.BF16
-    d.batch, d.t_in, d.h, d.w, d.c_in, d.c_out, d.kt, d.taps, d.pad_t = B, T, H, W, cin, cout, kt, taps, pad_t
+    d.batch, d.t_in, d.c_in, d.c_out, d.kt, d.taps, d.pad_t = B, T, cin, cout, kt, taps, pad_t
+    d.t_alloc, d.t_offset = (T if t_alloc is None else t_alloc), t_offset
     d.ld_x, d.ld_y, d.accumulate = ld_x, ld_y, acc
-    t_out = T + 2 * pad_t - kt + 1
-    d.x_batch_stride, d.y_batch_stride = T * H * W * ld_x, t_out * H * W * ld_y
-    return d, t_out
+    d.pyr = _lib.make_pyramid(shapes)
+    return d, T + 2 * pad_t - kt + 1
 
 
-def ndhwc(x_ncdhw, prec, ld=None):
-    """[B,C,T,H,W] fp32 cpu -> [B,T,H,W,ld] device tensor of the compute dtype (extra channels = junk 7.0)."""
-    B, C, T, H, W = x_ncdhw.shape
+def to_pyr(levels, prec, ld=None, fill=7.0):
+    """list over levels of [B,C,T,H,W] fp32 cpu -> flat pyramid buffer [M, ld] on the device."""
+    C = levels[0].shape[1]
     ld = ld or C
-    out = torch.full((B, T, H, W, ld), 7.0, dtype=torch.float32)
-    out[..., :C] = x_ncdhw.permute(0, 2, 3, 4, 1)
-    return out.to(TDT[prec]).cuda()
+    rows = []
+    for x in levels:
+        rows.append(x.permute(0, 2, 3, 4, 1).reshape(-1, C))
+    flat = torch.full((sum(r.shape[0] for r in rows), ld), fill, dtype=torch.float32)
+    flat[:, :C] = torch.cat(rows, 0)
+    return flat.to(TDT[prec]).cuda()
+
+
+def from_pyr(flat, B, C, T, shapes):
+    """flat [M, ld] device -> list of [B,C,T,H,W] fp32 cpu (first C channels)."""
+    out, off = [], 0
+    f = flat.float().cpu()
+    for (H, W) in shapes:
+        n = B * T * H * W
+        out.append(f[off:off + n, :C].reshape(B, T, H, W, C).permute(0, 4, 1, 2, 3))
+        off += n
+    return out
 
 
 CONV_CASES = [
-    # B  T   H   W  cin cout kt taps  (covers narrow / mid / wide families, ragged tiles, TT blocks)
-    (1, 4, 12, 21, 256, 192, 2, 9),
-    (1, 3, 9, 17, 256, 224, 2, 9),
-    (2, 7, 6, 10, 64, 32, 3, 9),
-    (1, 13, 20, 19, 32, 32, 2, 9),     # t_out 12 -> two frame blocks of 6
-    (1, 14, 5, 33, 32, 32, 4, 9),      # t_out 11
-    (1, 9, 18, 16, 32, 64, 5, 1),      # lateral, t_out 5 (TT 6)
-    (1, 5, 7, 40, 32, 64, 3, 1),
-    (1, 3, 10, 12, 64, 32, 2, 1),      # lateral dgrad shape (narrow, 1x1)
+    # B  T   shapes                      cin cout kt taps
+    (1, 4, [(12, 21)], 256, 192, 2, 9),
+    (1, 3, [(9, 17), (5, 40)], 256, 224, 2, 9),
+    (2, 7, [(6, 10), (3, 5), (1, 2)], 64, 32, 3, 9),
+    (1, 13, [(20, 19)], 32, 32, 2, 9),             # t_out 12 -> three frame blocks of 4
+    (1, 14, [(5, 33), (9, 9)], 32, 32, 4, 9),      # t_out 11
+    (1, 9, [(18, 16), (4, 35)], 32, 64, 5, 1),     # lateral, t_out 5
+    (1, 5, [(7, 40)], 32, 64, 3, 1),
+    (1, 3, [(10, 12), (3, 3)], 64, 32, 2, 1),      # lateral dgrad shape (narrow, 1x1)
 ]
 
 
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv3d_forward_bias_stats(lib, prec, case):
-    B, T, H, W, cin, cout, kt, taps = case
+    B, T, shapes, cin, cout, kt, taps = case
     g = torch.Generator().manual_seed(1234)
-    x = torch.randn(B, cin, T, H, W, generator=g)
     k = 3 if taps == 9 else 1
     w = torch.randn(cout, cin, kt, k, k, generator=g) / np.sqrt(cin * kt * taps)
     bias = torch.randn(cout, generator=g) * 0.1
+    xs = [torch.randn(B, cin, T, H, W, generator=g) for (H, W) in shapes]
     if prec == 'bf16':  # the reference sees the same rounded operands
-        x, w = x.bfloat16().float(), w.bfloat16().float()
-    ref = F.conv3d(x, w, bias, padding=(0, 1, 1) if taps == 9 else 0)
+        xs, w = [x.bfloat16().float() for x in xs], w.bfloat16().float()
+    refs = [F.conv3d(x, w, bias, padding=(0, 1, 1) if taps == 9 else 0) for x in xs]
     ld_x, ld_y = cin + 32, cout + 64
-    xd = ndhwc(x, prec, ld_x)
-    d, t_out = make_desc(lib, prec, B, T, H, W, cin, cout, kt, taps, 0, ld_x, ld_y)
-    wd = w.cuda()
+    xd = to_pyr(xs, prec, ld_x)
+    d, t_out = make_desc(lib, prec, B, T, shapes, cin, cout, kt, taps, 0, ld_x, ld_y)
     wp = torch.empty(w.numel(), dtype=TDT[prec], device='cuda')
-    lib.call('sfvos_pack_weights_fwd', P(wd), P(wp), d.dtype, cout, cin, kt, taps, S())
-    y = torch.full((B, t_out, H, W, ld_y), -3.0, dtype=TDT[prec], device='cuda')
-    rows = lib.load().sfvos_conv3d_stat_rows(ctypes.byref(d))
-    assert rows > 0
+    lib.call('sfvos_pack_weights_fwd', P(w.cuda()), P(wp), d.dtype, cout, cin, kt, taps, S())
+    M = sum(B * t_out * H * W for H, W in shapes)
+    y = torch.full((M, ld_y), -3.0, dtype=TDT[prec], device='cuda')
+    rows_pl = (ctypes.c_int * lib.MAX_LEVELS)()
+    rows = lib.load().sfvos_conv3d_stat_rows(ctypes.byref(d), rows_pl)
+    assert rows > 0 and sum(rows_pl[:len(shapes)]) == rows
     part = torch.full((rows, 2, cout), 1e9, dtype=torch.float32, device='cuda')
     zeros = torch.zeros(1024, dtype=torch.uint8, device='cuda')
     lib.call('sfvos_conv3d', ctypes.byref(d), P(xd), P(wp), P(bias.cuda()), P(y), P(part), P(zeros), S())
     torch.cuda.synchronize()
-    got = y[..., :cout].float().cpu().permute(0, 4, 1, 2, 3)
-    assert relmax(got, ref) < TOL[prec]
-    assert torch.all(y[..., cout:].float() == -3.0), 'wrote outside its channel slice'
-    s = part.double().sum(0).cpu()
-    ref_s1 = ref.double().sum((0, 2, 3, 4))
-    ref_s2 = (ref.double() ** 2).sum((0, 2, 3, 4))
-    n = B * t_out * H * W
-    assert float((s[0] - ref_s1).abs().max()) / n < 1e-3 * float(ref.abs().max())
-    assert relmax(s[1], ref_s2) < (1e-4 if prec == 'fp32' else 2e-2)
+    got = from_pyr(y, B, cout, t_out, shapes)
+    r0 = 0
+    for l, ref in enumerate(refs):
+        assert relmax(got[l], ref) < TOL[prec], 'level %d' % l
+        s = part[r0:r0 + rows_pl[l]].double().sum(0).cpu()
+        r0 += rows_pl[l]
+        n = ref.numel() // cout
+        assert float((s[0] - ref.double().sum((0, 2, 3, 4))).abs().max()) / n < 1e-3 * float(ref.abs().max())
+        assert relmax(s[1], (ref.double() ** 2).sum((0, 2, 3, 4))) < (1e-4 if prec == 'fp32' else 2e-2)
+    assert torch.all(y[:, cout:].float() == -3.0), 'wrote outside its channel slice'
 
 
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
-@pytest.mark.parametrize('case', [(1, 4, 12, 21, 256, 192, 2, 9), (1, 13, 10, 19, 32, 32, 2, 9),
-                                  (1, 9, 9, 16, 32, 64, 5, 1), (1, 7, 6, 10, 256, 32, 3, 9)])
+def test_conv3d_reads_a_frame_window_of_a_longer_clip(lib, prec):
+    """t_alloc/t_offset: the slow pathway reads its centre frames out of the fast clip's buffer."""
+    B, Tf, sp, off, shapes, cin, cout, kt = 2, 7, 3, 2, [(6, 10), (3, 7)], 64, 32, 2
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(cout, cin, kt, 3, 3, generator=g) / np.sqrt(cin * kt * 9)
+    xs = [torch.randn(B, cin, Tf, H, W, generator=g) for (H, W) in shapes]
+    if prec == 'bf16':
+        xs, w = [x.bfloat16().float() for x in xs], w.bfloat16().float()
+    refs = [F.conv3d(x[:, :, off:off + sp], w, None, padding=(0, 1, 1)) for x in xs]
+    xd = to_pyr(xs, prec)
+    d, t_out = make_desc(lib, prec, B, sp, shapes, cin, cout, kt, 9, 0, cin, cout, t_alloc=Tf, t_offset=off)
+    wp = torch.empty(w.numel(), dtype=TDT[prec], device='cuda')
+    lib.call('sfvos_pack_weights_fwd', P(w.cuda()), P(wp), d.dtype, cout, cin, kt, 9, S())
+    y = torch.empty((sum(B * t_out * H * W for H, W in shapes), cout), dtype=TDT[prec], device='cuda')
+    zeros = torch.zeros(1024, dtype=torch.uint8, device='cuda')
+    lib.call('sfvos_conv3d', ctypes.byref(d), P(xd), P(wp), None, P(y), None, P(zeros), S())
+    for a, b in zip(from_pyr(y, B, cout, t_out, shapes), refs):
+        assert relmax(a, b) < TOL[prec]
+    # weight gradient through the same window
+    dys = [torch.randn(B, cout, t_out, H, W, generator=g) for (H, W) in shapes]
+    if prec == 'bf16':
+        dys = [v.bfloat16().float() for v in dys]
+    wz = torch.zeros_like(w, requires_grad=True)
+    for x, dy in zip(xs, dys):
+        F.conv3d(x[:, :, off:off + sp], wz, None, padding=(0, 1, 1)).backward(dy)
+    dyd = to_pyr(dys, prec)
+    ws = torch.empty(lib.load().sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d)), dtype=torch.uint8, device='cuda')
+    gw = torch.empty(w.shape, dtype=torch.float32, device='cuda')
+    lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(xd), P(dyd), P(gw), 0, P(ws), P(zeros), S())
+    assert relmax(gw.cpu(), wz.grad) < TOL[prec]
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('case', [(1, 4, [(12, 21)], 256, 192, 2, 9), (1, 13, [(10, 19), (4, 5)], 32, 32, 2, 9),
+                                  (1, 9, [(9, 16)], 32, 64, 5, 1), (1, 7, [(6, 10), (2, 3)], 256, 32, 3, 9)])
 def test_conv3d_dgrad_and_accumulate(lib, prec, case):
-    B, T, H, W, cin, cout, kt, taps = case
+    B, T, shapes, cin, cout, kt, taps = case
     g = torch.Generator().manual_seed(99)
     k = 3 if taps == 9 else 1
-    x = torch.randn(B, cin, T, H, W, generator=g, requires_grad=True)
     w = torch.randn(cout, cin, kt, k, k, generator=g) / np.sqrt(cout * kt * taps)
     t_out = T - kt + 1
-    dy = torch.randn(B, cout, t_out, H, W, generator=g)
+    xs = [torch.randn(B, cin, T, H, W, generator=g, requires_grad=True) for (H, W) in shapes]
+    dys = [torch.randn(B, cout, t_out, H, W, generator=g) for (H, W) in shapes]
     if prec == 'bf16':
-        w, dy = w.bfloat16().float(), dy.bfloat16().float()
-    F.conv3d(x, w, None, padding=(0, 1, 1) if taps == 9 else 0).backward(dy)
-    ref = x.grad
-    dyd = ndhwc(dy, prec)
+        w, dys = w.bfloat16().float(), [v.bfloat16().float() for v in dys]
+    for x, dy in zip(xs, dys):
+        F.conv3d(x, w, None, padding=(0, 1, 1) if taps == 9 else 0).backward(dy)
+    dyd = to_pyr(dys, prec)
     # the data-gradient conv: channels swapped, pad_t = kt-1
-    d, t_back = make_desc(lib, prec, B, t_out, H, W, cout, cin, kt, taps, kt - 1, cout, cin)
+    d, t_back = make_desc(lib, prec, B, t_out, shapes, cout, cin, kt, taps, kt - 1, cout, cin)
     assert t_back == T
     wp = torch.empty(w.numel(), dtype=TDT[prec], device='cuda')
     lib.call('sfvos_pack_weights_dgrad', P(w.cuda()), P(wp), d.dtype, cout, cin, kt, taps, S())
-    dx = torch.empty((B, T, H, W, cin), dtype=TDT[prec], device='cuda')
+    dx = torch.empty((sum(B * T * H * W for H, W in shapes), cin), dtype=TDT[prec], device='cuda')
     zeros = torch.zeros(1024, dtype=torch.uint8, device='cuda')
     lib.call('sfvos_conv3d', ctypes.byref(d), P(dyd), P(wp), None, P(dx), None, P(zeros), S())
-    got = dx.float().cpu().permute(0, 4, 1, 2, 3)
-    assert relmax(got, ref) < TOL[prec]
+    for a, x in zip(from_pyr(dx, B, cin, T, shapes), xs):
+        assert relmax(a, x.grad) < TOL[prec]
     d.accumulate = 1  # second call adds: dx == 2 * grad
     lib.call('sfvos_conv3d', ctypes.byref(d), P(dyd), P(wp), None, P(dx), None, P(zeros), S())
-    got2 = dx.float().cpu().permute(0, 4, 1, 2, 3)
-    assert relmax(got2, 2 * ref) < 2 * TOL[prec]
+    for a, x in zip(from_pyr(dx, B, cin, T, shapes), xs):
+        assert relmax(a, 2 * x.grad) < 2 * TOL[prec]
 
 
 WGRAD_CASES = [
-    (1, 4, 12, 21, 256, 32, 2, 9),    # cfg A (c_out 32, c_in 256)
-    (1, 3, 9, 17, 256, 192, 2, 9),    # cfg B
-    (1, 3, 6, 10, 256, 224, 2, 9),    # cfg B, ragged n blocks
-    (2, 13, 7, 19, 32, 32, 11, 9),    # cfg C, kt 11 -> two dt groups
-    (1, 9, 18, 16, 32, 64, 5, 1),     # cfg D (lateral)
-    (1, 24, 5, 33, 32, 64, 20, 1),
+    (1, 4, [(12, 21), (6, 10)], 256, 32, 2, 9),    # cfg (1,2,4): c_out 32, c_in 256
+    (1, 3, [(9, 17)], 256, 192, 2, 9),             # cfg (2,2,2)
+    (1, 3, [(6, 10), (3, 4)], 256, 224, 2, 9),     # ragged n blocks
+    (2, 13, [(7, 19), (9, 3)], 32, 32, 11, 9),     # cfg (1,1,8), kt 11 -> two dt groups
+    (1, 9, [(18, 16)], 32, 64, 5, 1),              # cfg (2,1,4) lateral
+    (1, 24, [(5, 33), (2, 2)], 32, 64, 20, 1),
 ]
 
 
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 @pytest.mark.parametrize('case', WGRAD_CASES)
 def test_conv3d_wgrad(lib, prec, case):
-    B, T, H, W, cin, cout, kt, taps = case
+    B, T, shapes, cin, cout, kt, taps = case
     g = torch.Generator().manual_seed(7)
     k = 3 if taps == 9 else 1
-    x = torch.randn(B, cin, T, H, W, generator=g)
     w = torch.zeros(cout, cin, kt, k, k, requires_grad=True)
     t_out = T - kt + 1
-    dy = torch.randn(B, cout, t_out, H, W, generator=g)
+    xs = [torch.randn(B, cin, T, H, W, generator=g) for (H, W) in shapes]
+    dys = [torch.randn(B, cout, t_out, H, W, generator=g) for (H, W) in shapes]
     if prec == 'bf16':
-        x, dy = x.bfloat16().float(), dy.bfloat16().float()
-    F.conv3d(x, w, None, padding=(0, 1, 1) if taps == 9 else 0).backward(dy)
+        xs, dys = [v.bfloat16().float() for v in xs], [v.bfloat16().float() for v in dys]
+    for x, dy in zip(xs, dys):
+        F.conv3d(x, w, None, padding=(0, 1, 1) if taps == 9 else 0).backward(dy)
     ref = w.grad
     ld_x, ld_y = cin + 32, cout + 32
-    xd, dyd = ndhwc(x, prec, ld_x), ndhwc(dy, prec, ld_y)
-    d, _ = make_desc(lib, prec, B, T, H, W, cin, cout, kt, taps, 0, ld_x, ld_y)
+    xd, dyd = to_pyr(xs, prec, ld_x), to_pyr(dys, prec, ld_y)
+    d, _ = make_desc(lib, prec, B, T, shapes, cin, cout, kt, taps, 0, ld_x, ld_y)
     nbytes = lib.load().sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
     assert nbytes > 0
     ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
@@ -203,57 +253,72 @@ def test_layout_roundtrip_and_strided_source(lib, prec):
     assert torch.equal(again.cpu(), dst[0].reshape(M, C).cpu())
 
 
+def _levels(lib, ms):
+    lv = lib.Levels()
+    lv.n_levels = len(ms)
+    for i, m in enumerate(ms):
+        lv.m[i] = m
+    return lv
+
+
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 @pytest.mark.parametrize('C,relu', [(192, 1), (224, 0), (32, 1), (64, 1)])
-def test_batchnorm_forward_backward(lib, prec, C, relu):
-    M = 3 * 11 * 23
+def test_batchnorm_forward_backward_per_level(lib, prec, C, relu):
+    ms = [3 * 11 * 23, 700, 37]          # three levels with their own statistics
+    L, M = len(ms), sum(ms)
     g = torch.Generator().manual_seed(11)
-    x = (torch.randn(M, C, generator=g) * 1.7 + 0.3)
-    dy = torch.randn(M, C, generator=g)
     gamma = torch.rand(C, generator=g) + 0.5
     beta = torch.randn(C, generator=g) * 0.2
+    xs = [torch.randn(m, C, generator=g) * (1.0 + 0.7 * i) + 0.3 * i for i, m in enumerate(ms)]
+    dys = [torch.randn(m, C, generator=g) for m in ms]
     if prec == 'bf16':
-        x, dy = x.bfloat16().float(), dy.bfloat16().float()
+        xs, dys = [v.bfloat16().float() for v in xs], [v.bfloat16().float() for v in dys]
     dt = lib.F32 if prec == 'fp32' else lib.BF16
-    xr = x.clone().requires_grad_(True)
     gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     rm, rv = torch.zeros(C), torch.ones(C)
-    yr = F.batch_norm(xr.t().reshape(1, C, M), rm, rv, gr, br, True, 0.1, 1e-5)
-    yr = F.relu(yr) if relu else yr
-    yr.backward(dy.t().reshape(1, C, M))
-    # forward statistics from a single "partial row" (sum, sumsq)
-    part = torch.stack([x.double().sum(0), (x.double() ** 2).sum(0)]).float().reshape(1, 2, C).cuda()
-    cf = torch.empty((5, C), dtype=torch.float32, device='cuda')
+    ref_y, ref_dx = [], []
+    for x, dy in zip(xs, dys):   # the reference: one BN call per level, running stats updated in order
+        xr = x.clone().requires_grad_(True)
+        yr = F.batch_norm(xr.t().reshape(1, C, -1), rm, rv, gr, br, True, 0.1, 1e-5)
+        yr = F.relu(yr) if relu else yr
+        yr.backward(dy.t().reshape(1, C, -1))
+        ref_y.append(yr.detach().reshape(C, -1).t())
+        ref_dx.append(xr.grad)
+    # forward statistics from one "partial row" (sum, sumsq) per level
+    part = torch.stack([torch.stack([x.double().sum(0), (x.double() ** 2).sum(0)]) for x in xs]).float().cuda()
+    cf = torch.zeros((L, 8, C), dtype=torch.float32, device='cuda')
+    cs = 8 * C
     gd, bd = gamma.cuda(), beta.cuda()
-    lib.call('sfvos_bn_finalize', P(part), 1, M, P(gd), P(bd), 1e-5, C, P(cf[0]), P(cf[1]), P(cf[2]), P(cf[3]),
-             P(cf[4]), S())
+    rows_pl = (ctypes.c_int * lib.MAX_LEVELS)(*([1] * L))
+    lv = _levels(lib, ms)
+    lib.call('sfvos_bn_finalize', P(part), L, rows_pl, lv.m, P(gd), P(bd), 1e-5, C, P(cf[0, 0]), P(cf[0, 1]),
+             P(cf[0, 2]), P(cf[0, 3]), P(cf[0, 4]), cs, S())
     rmd, rvd = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
-    lib.call('sfvos_bn_running_update', P(rmd), P(rvd), P(cf[0]), P(cf[4]), 1, C, 0.1, S())
+    lib.call('sfvos_bn_running_update', P(rmd), P(rvd), P(cf[0, 0]), P(cf[0, 4]), L, cs, C, 0.1, S())
     assert relmax(rmd.cpu(), rm) < 1e-5 and relmax(rvd.cpu(), rv) < 1e-5
     ld = C + 32
-    xd = torch.zeros((M, C), dtype=TDT[prec], device='cuda').copy_(x)
+    xd = torch.cat(xs).to(TDT[prec]).cuda()
     y = torch.full((M, ld), 9.0, dtype=TDT[prec], device='cuda')
-    lib.call('sfvos_bn_apply', P(xd), C, P(y, 32), ld, dt, M, C, P(cf[2]), P(cf[3]), relu, S())
-    ref_y = yr.detach().reshape(C, M).t()
-    assert relmax(y[:, 32:].float().cpu(), ref_y) < (1e-5 if prec == 'fp32' else 8e-3)
+    lib.call('sfvos_bn_apply', P(xd), C, P(y, 32), ld, dt, ctypes.byref(lv), C, P(cf[0, 2]), P(cf[0, 3]), cs, relu, S())
+    assert relmax(y[:, 32:].float().cpu(), torch.cat(ref_y)) < (1e-5 if prec == 'fp32' else 8e-3)
     assert torch.all(y[:, :32].float() == 9.0)
     # backward
     dyd = torch.zeros((M, ld), dtype=TDT[prec], device='cuda')
-    dyd[:, 32:] = dy.to(TDT[prec])
-    rows = lib.load().sfvos_bn_bwd_rows(M)
+    dyd[:, 32:] = torch.cat(dys).to(TDT[prec])
+    rows = lib.load().sfvos_bn_bwd_rows(ctypes.byref(lv))
+    assert rows >= L
     bpart = torch.empty((rows, 2, C), dtype=torch.float32, device='cuda')
-    lib.call('sfvos_bn_bwd_reduce', P(dyd, 32), ld, P(xd), C, dt, M, C, P(cf[2]), P(cf[3]), P(cf[0]), P(cf[1]), relu,
-             P(bpart), S())
+    lib.call('sfvos_bn_bwd_reduce', P(dyd, 32), ld, P(xd), C, dt, ctypes.byref(lv), C, P(cf[0, 2]), P(cf[0, 3]),
+             P(cf[0, 0]), P(cf[0, 1]), cs, relu, P(bpart), S())
     dg, db = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
-    abk = torch.empty((3, C), device='cuda')
-    lib.call('sfvos_bn_bwd_finalize', P(bpart), rows, M, P(gd), P(cf[0]), P(cf[1]), C, 1, 0, P(dg), P(db), P(abk[0]),
-             P(abk[1]), P(abk[2]), S())
+    lib.call('sfvos_bn_bwd_finalize', P(bpart), ctypes.byref(lv), P(gd), P(cf[0, 0]), P(cf[0, 1]), cs, C, 1, 0, P(dg),
+             P(db), P(cf[0, 5]), P(cf[0, 6]), P(cf[0, 7]), S())
     assert relmax(dg.cpu(), gr.grad) < 1e-4 and relmax(db.cpu(), br.grad) < 1e-4
     dx = torch.empty((M, C), dtype=TDT[prec], device='cuda')
     biasp = torch.empty((rows, C), dtype=torch.float32, device='cuda')
-    lib.call('sfvos_bn_bwd_apply', P(dyd, 32), ld, P(xd), C, P(dx), C, dt, M, C, P(cf[2]), P(cf[3]), relu, P(abk[0]),
-             P(abk[1]), P(abk[2]), P(biasp), S())
-    assert relmax(dx.float().cpu(), xr.grad) < (1e-4 if prec == 'fp32' else 1e-2)
+    lib.call('sfvos_bn_bwd_apply', P(dyd, 32), ld, P(xd), C, P(dx), C, dt, ctypes.byref(lv), C, P(cf[0, 2]),
+             P(cf[0, 3]), cs, relu, P(cf[0, 5]), P(cf[0, 6]), P(cf[0, 7]), P(biasp), S())
+    assert relmax(dx.float().cpu(), torch.cat(ref_dx)) < (1e-4 if prec == 'fp32' else 1e-2)
     dbias = torch.empty(C, device='cuda')
     lib.call('sfvos_reduce_rows', P(biasp), rows, C, P(dbias), 0, S())
     assert float(dbias.abs().max()) < 1e-2 * float(dx.float().abs().sum(0).max())  # sums to ~0 in train mode
@@ -278,8 +343,10 @@ def test_sgd_step_and_scale(lib):
 
 
 def test_bad_arguments_report_errors(lib):
-    d, _ = make_desc(lib, 'fp32', 1, 4, 8, 8, 48, 32, 2, 9, 0, 48, 32)  # c_in not a multiple of 32
-    assert lib.load().sfvos_conv3d_stat_rows(ctypes.byref(d)) < 0
+    d, _ = make_desc(lib, 'fp32', 1, 4, [(8, 8)], 48, 32, 2, 9, 0, 48, 32)  # c_in not a multiple of 32
+    assert lib.load().sfvos_conv3d_stat_rows(ctypes.byref(d), None) < 0
     assert b'multiples of 32' in lib.load().sfvos_last_error()
+    d, _ = make_desc(lib, 'fp32', 1, 4, [(8, 8)], 64, 32, 2, 9, 0, 64, 32, t_alloc=3)  # window outside the buffer
+    assert lib.load().sfvos_conv3d_stat_rows(ctypes.byref(d), None) < 0
     with pytest.raises(RuntimeError):
         lib.call('sfvos_scale', None, 10, 1.0, S())

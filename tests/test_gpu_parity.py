@@ -184,28 +184,57 @@ def test_bf16_path_error_is_bounded(sp, fp):
 
 
 def test_full_size_properties_headline_config():
-    """(sp,fp)=(4,32) at DAVIS level '1' (96x168) and level '3' (24x42), bf16:
-    determinism (no atomics anywhere), train-mode BN invariants of the fused map
-    (per-channel mean == beta, var == gamma^2 * var/(var+eps)), and agreement with the fp32 path."""
+    """(sp,fp)=(4,32) on a pyramid of DAVIS levels '1','3','pool' (96x168, 24x42, 12x21) handed over as a
+    PackedClip, bf16: determinism (no atomics anywhere), train-mode BN invariants of the fused map per level
+    (per-channel mean == beta, std == |gamma|), and agreement with the fp32 path."""
+    from sfvos_amd import PackedClip
     torch.manual_seed(0)
-    for (H, W) in ((96, 168), (24, 42)):
-        m, dev = build(4, 32, 'bf16')
-        m.train()
-        g = torch.Generator(device='cuda').manual_seed(63)
-        fast = torch.randn(1, 32, H, W, 256, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
-        slow = fast[:, 14:18].contiguous()
-        with torch.no_grad():
-            a = m.temporally_enhance_features_ndhwc({'l': slow}, {'l': fast})['l']
-            b = m.temporally_enhance_features_ndhwc({'l': slow}, {'l': fast})['l']
-        assert torch.equal(a, b), 'two runs differ: the path must be deterministic'
-        mean = a.double().mean((0, 2, 3)).cpu()
-        var = a.double().var((0, 2, 3), unbiased=False).cpu()
-        beta = torch.cat([m.bn_s3.bias, m.bn_f3.bias]).detach().double().cpu()
-        gamma = torch.cat([m.bn_s3.weight, m.bn_f3.weight]).detach().double().cpu()
+    shapes = [(96, 168), (24, 42), (12, 21)]
+    m, dev = build(4, 32, 'bf16')
+    m.train()
+    g = torch.Generator(device='cuda').manual_seed(63)
+    levels = [torch.randn(1, 32, H, W, 256, generator=g, device=dev, dtype=torch.float32) for (H, W) in shapes]
+    clip = PackedClip.from_levels([x.to(torch.bfloat16) for x in levels], keys=['1', '3', 'pool'])
+    with torch.no_grad():
+        a = m.enhance_packed(clip)
+        b = m.enhance_packed(clip)
+    assert list(a.keys()) == ['1', '3', 'pool']
+    m32, _ = build(4, 32, 'fp32')
+    m32.train()
+    with torch.no_grad():
+        c = m32.enhance_packed(PackedClip.from_levels([x.to(torch.bfloat16).float() for x in levels],
+                                                      keys=['1', '3', 'pool']))
+    beta = torch.cat([m.bn_s3.bias, m.bn_f3.bias]).detach().double().cpu()
+    gamma = torch.cat([m.bn_s3.weight, m.bn_f3.weight]).detach().double().cpu()
+    for k, (H, W) in zip(a.keys(), shapes):
+        assert tuple(a[k].shape) == (1, 256, H, W)
+        assert torch.equal(a[k], b[k]), 'two runs differ: the path must be deterministic'
+        mean = a[k].double().mean((0, 2, 3)).cpu()
+        var = a[k].double().var((0, 2, 3), unbiased=False).cpu()
         assert float((mean - beta).abs().max()) < 2e-2
         assert float((var.sqrt() - gamma.abs()).abs().max()) < 2e-2
-        m32, _ = build(4, 32, 'fp32')
-        m32.train()
-        with torch.no_grad():
-            c = m32.temporally_enhance_features_ndhwc({'l': slow.float()}, {'l': fast.float()})['l']
-        assert max_rel_err(a.cpu().numpy(), c.cpu().numpy()) < 5e-2
+        assert max_rel_err(a[k].cpu().numpy(), c[k].cpu().numpy()) < 5e-2
+
+
+def test_packed_clip_matches_frame_lists_and_backward():
+    """enhance_packed (channels-last hand-over) == temporally_enhance_features on the same data,
+    forward and parameter gradients, fp32."""
+    from sfvos_amd import PackedClip
+    sp, fp = 3, 7
+    m, dev = build(sp, fp, 'fp32')
+    m.train()
+    slow, fast = clip_inputs(sp, fp, SMALL_LEVELS, 0, dev)
+    out = m.temporally_enhance_features(slow, fast)
+    proxy_loss(out).backward()
+    ref_g = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad()
+    m2, _ = build(sp, fp, 'fp32')
+    m2.train()
+    levels = [fast[0][k].permute(0, 2, 3, 1).unsqueeze(0).contiguous() for k in SMALL_LEVELS]   # [1,T,H,W,C]
+    clip = PackedClip.from_levels(levels, keys=list(SMALL_LEVELS.keys()))
+    out2 = m2.enhance_packed(clip)
+    proxy_loss(out2).backward()
+    for k in out:
+        assert torch.equal(out[k], out2[k])
+    for k, p in m2.named_parameters():
+        assert torch.equal(p.grad, ref_g[k]), k

@@ -106,8 +106,9 @@ def test_cabi_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     lib.sfvos_version.restype = ctypes.c_int
     assert lib.sfvos_version() >= 100
-    # struct mirror: size must match the C struct (13 ints + padding + 2 int64 = 72 bytes)
-    assert ctypes.sizeof(_lib.ConvDesc) == 72
+    # struct mirrors: sizes must match the C structs (13 ints + sfvos_pyramid{int, int[8], int[8]})
+    assert ctypes.sizeof(_lib.Pyramid) == 68 and ctypes.sizeof(_lib.ConvDesc) == 120
+    assert ctypes.sizeof(_lib.Levels) == 72
 
 
 def test_shard_clips():
