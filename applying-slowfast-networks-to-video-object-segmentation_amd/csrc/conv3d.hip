@@ -25,6 +25,17 @@
 
 #include "common.h"
 
+// Diagnostic stamps (scratch builds with -DSFVOS_STAMP only; never in the shipped library).
+#ifdef SFVOS_STAMP
+#define SFVOS_STAMP_AT(idx)                                                                   \
+  if (a.stamps && blockIdx.x == 300 && s < 128) {                                             \
+    const unsigned long long tstamp = __builtin_amdgcn_s_memtime();                           \
+    if (lane == 0) a.stamps[(wv * 128 + s) * 4 + (idx)] = tstamp;                             \
+  }
+#else
+#define SFVOS_STAMP_AT(idx)
+#endif
+
 namespace sfvos {
 
 struct ConvLevels {
@@ -46,6 +57,9 @@ struct ConvArgs {
   int batch, t_in, t_alloc, t_offset, t_out, c_in, c_out, kt, pad_t, ld_x, ld_y, accumulate;
   int t_blocks, n_blocks;
   int debug;  // timing-only: bit0 skip compute, bit1 skip DMA after the first stage (results wrong)
+#ifdef SFVOS_STAMP
+  unsigned long long* stamps;  // diagnostic build only: s_memtime stamps of one workgroup
+#endif
   ConvLevels lv;
 };
 
@@ -68,7 +82,7 @@ struct ConvCfg {
 };
 
 template <int DT, int TAPS, int TPS, int TT, int MT, int NT, int WS, int WN>
-__global__ __launch_bounds__(64 * WS * WN) void conv3d_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WS * WN, (WS * WN) / 4) void conv3d_kernel(ConvArgs a) {
   typedef ConvCfg<DT, TAPS, TPS, TT, MT, NT, WS, WN> C;
   typedef typename Elt<DT>::type T;
   constexpr int CE = Elt<DT>::CE, CK = 4 * CE, ES = 16 / CE;
@@ -87,17 +101,23 @@ __global__ __launch_bounds__(64 * WS * WN) void conv3d_kernel(ConvArgs a) {
   for (int l = 1; l < SFVOS_MAX_LEVELS; ++l)
     if (l < a.lv.n && (int)blockIdx.x >= a.lv.wg_begin[l]) lvl = l;
   const int H = a.lv.H[lvl], W = a.lv.W[lvl], tiles_w = a.lv.tiles_w[lvl], tiles_h = a.lv.tiles_h[lvl];
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (speed only, never
+  // correctness), so the t_blocks frame blocks of one pixel tile -- which stream the same input
+  // frames -- get ids that are equal mod 8 and adjacent in time: they share one XCD's L2.
   int bid = blockIdx.x - a.lv.wg_begin[lvl];
-  const int tw = bid % tiles_w; bid /= tiles_w;
-  const int th = bid % tiles_h; bid /= tiles_h;
-  const int nb = bid % a.n_blocks; bid /= a.n_blocks;
-  const int tb = bid % a.t_blocks; bid /= a.t_blocks;
-  const int b = bid;
+  const int per_group = 8 * a.t_blocks;
+  const int grp = bid / per_group, rem = bid - grp * per_group;
+  const int tb = rem >> 3;
+  const int ntile = tiles_h * tiles_w, tgroups = (ntile + 7) >> 3;
+  const int tile = (grp % tgroups) * 8 + (rem & 7);
+  if (tile >= ntile) return;  // padding workgroup (whole workgroup, before any barrier)
+  const int bn = grp / tgroups;
+  const int nb = bn % a.n_blocks, b = bn / a.n_blocks;
+  const int th = tile / tiles_w, tw = tile - th * tiles_w;
   const int h0 = th * C::TH, w0 = tw * C::TW, n0 = nb * C::BN, tb0 = tb * TT;
 
   const int NF = TT + a.kt - 1;  // input frames this workgroup touches: t = tb0 - pad_t + i
   const int ncc = a.c_in / CK;
-  const int S = ncc * a.kt * C::NTG;
   const long long HWp = (long long)H * W;
   // frame 0 of this clip inside the x buffer (t_alloc frames per clip, the conv's window starts at t_offset)
   const char* xclip = a.x + (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset) * HWp) * a.ld_x * ES;
@@ -112,47 +132,81 @@ __global__ __launch_bounds__(64 * WS * WN) void conv3d_kernel(ConvArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][i][q][e] = 0.f;
 
-  // ---- DMA: one ring frame (halo tile of input frame i, channel chunk cc) ----------------------
-  auto issue_frame = [&](int cc, int i) {
-    const int t = tb0 - a.pad_t + i;
-    const bool t_ok = (unsigned)t < (unsigned)a.t_in;
-    char* xb = ring + ((cc * NF + i) % C::R) * C::X_BYTES;
-    const char* xsrc = xclip + ((long long)t * HWp * a.ld_x + cc * CK) * ES;
+  // ---- DMA source offsets: a thread copies the same slots of every ring frame / weight slice, so its
+  // byte offsets (relative to the frame / slice base) are computed ONCE; per stage only a base is added
+  // (keeps the VALU out of the way of the MFMA stream).
+  constexpr int NX = (C::X_SLOTS + C::NTHREADS - 1) / C::NTHREADS;
+  constexpr int NW = (C::W_SLOTS + C::NTHREADS - 1) / C::NTHREADS;
+  int xo[NX], wo[NW];  // >= 0 offset ; -1 zero page (padding) ; -2 no slot
 #pragma unroll
-    for (int it = 0; it < (C::X_SLOTS + C::NTHREADS - 1) / C::NTHREADS; ++it) {
-      const int sl = it * C::NTHREADS + tid;
-      if (sl < C::X_SLOTS) {
-        const int col = sl % C::HC, rowj = sl / C::HC, row = rowj % C::HR, j = rowj / C::HR;
-        const int h = h0 + row - C::HALO, w = w0 + col - C::HALO;
-        const bool ok = t_ok && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
-        const char* src = ok ? xsrc + ((long long)(h * W + w) * a.ld_x + j * CE) * ES : a.zeros;
-        glds16(src, xb + (sl - lane) * 16);
+  for (int it = 0; it < NX; ++it) {
+    const int sl = it * C::NTHREADS + tid;
+    const int col = sl % C::HC, rowj = sl / C::HC, row = rowj % C::HR, j = rowj / C::HR;
+    const int h = h0 + row - C::HALO, w = w0 + col - C::HALO;
+    const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+    xo[it] = sl >= C::X_SLOTS ? -2 : (ok ? (int)((((long long)h * W + w) * a.ld_x + j * CE) * ES) : -1);
+  }
+#pragma unroll
+  for (int it = 0; it < NW; ++it) {
+    const int sl = it * C::NTHREADS + tid;
+    const int tj = sl / C::BN, n = sl - tj * C::BN;  // tj = tap_local*4 + chunk
+    wo[it] = (sl < C::W_SLOTS && n0 + n < a.c_out) ? (tj * a.c_out + n) * 16 : -2;
+  }
+  const int lds_wave_off = wv * 1024;  // (sl - lane) * 16 = it * NTHREADS * 16 + wave * 1024
+
+  // ---- DMA descriptors: the scalars of a copy are prepared at stage start; the copy itself is issued
+  // piece by piece (one global_load_lds wave-instruction per piece) between the MFMA groups of the
+  // stage, so its address arithmetic runs in the shadow of the matrix pipe instead of in front of it.
+  struct Dma {
+    const char* xsrc; char* xb; bool do_x, t_ok;
+    const char* wsrc; char* wb; bool do_w;
+  };
+  constexpr int NPIECE = NX + NW;
+  auto wrap = [](int sl) { return sl >= C::R ? sl - C::R : sl; };
+  auto prep_frame = [&](Dma& d, int cc, int i, int slot) {  // halo tile of input frame i, chunk cc -> ring slot
+    const int t = tb0 - a.pad_t + i;
+    d.do_x = true;
+    d.t_ok = (unsigned)t < (unsigned)a.t_in;
+    d.xb = ring + slot * C::X_BYTES + lds_wave_off;
+    d.xsrc = xclip + ((long long)t * HWp * a.ld_x + cc * CK) * ES;
+  };
+  auto prep_w = [&](Dma& d, int cc, int dt, int tg, int s) {  // weight slice of stage s: [TPS taps][4 chunks][BN]
+    d.do_w = true;
+    d.wb = wbase + (s & 1) * C::W_BYTES + lds_wave_off;
+    d.wsrc = a.wp + (((long long)(cc * a.kt + dt) * TAPS + tg * TPS) * 4 * a.c_out + n0) * 16;
+  };
+  auto piece = [&](const Dma& d, int p) {
+    if (p < NX) {
+      if (d.do_x && xo[p] > -2) {
+        const char* src = (d.t_ok && xo[p] >= 0) ? d.xsrc + xo[p] : a.zeros;
+        glds16(src, d.xb + p * (C::NTHREADS * 16));
       }
+    } else {
+      const int q = p - NX;
+      if (d.do_w && wo[q] > -2) glds16(d.wsrc + wo[q], d.wb + q * (C::NTHREADS * 16));
     }
   };
-  // ---- DMA: weight slice of stage s = (cc, dt, tg): [TPS taps][4 chunks][BN] -------------------
-  auto issue_w = [&](int cc, int dt, int tg, int s) {
-    char* wb = wbase + (s & 1) * C::W_BYTES;
-    const char* wsrc = a.wp + (((long long)(cc * a.kt + dt) * TAPS + tg * TPS) * 4 * a.c_out + n0) * 16;
+  auto issue_all = [&](const Dma& d) {
 #pragma unroll
-    for (int it = 0; it < (C::W_SLOTS + C::NTHREADS - 1) / C::NTHREADS; ++it) {
-      const int sl = it * C::NTHREADS + tid;
-      if (sl < C::W_SLOTS) {
-        const int tj = sl / C::BN, n = sl - tj * C::BN;  // tj = tap_local*4 + chunk
-        if (n0 + n < a.c_out) glds16(wsrc + ((long long)tj * a.c_out + n) * 16, wb + (sl - lane) * 16);
-      }
-    }
+    for (int p = 0; p < NPIECE; ++p) piece(d, p);
   };
 
-  // ---- one stage of MFMAs --------------------------------------------------------------------------
-  auto compute = [&](int cc, int dt, int tg, int s) {
-    const char* wb = wbase + (s & 1) * C::W_BYTES;
-    const char* xf[TT];
+  // ---- one stage of MFMAs (+ the next stage's DMA, interleaved) -------------------------------------
+  auto compute = [&](int tg, int s, int fslot, const Dma& d) {
+    // per-stage operand bases: lane part + ring slot / weight buffer; every read below adds only a
+    // compile-time constant, which folds into the ds_read offset field (no VALU per read)
+    const char* wbl = wbase + (s & 1) * C::W_BYTES + (hh * C::BN + wn * NT * 32 + r) * 16;
+    const char* xfl[TT];
 #pragma unroll
-    for (int j = 0; j < TT; ++j) xf[j] = ring + ((cc * NF + dt + j) % C::R) * C::X_BYTES;
-    // k-step k = (tap_local, st): operand fragments of step k+1 are read from LDS while the MFMAs
-    // of step k run (software pipeline in registers; the waits become counted, not lgkmcnt(0)).
-    u32x4 bv[2][NT], av[2][TT][MT];
+    for (int j = 0; j < TT; ++j)
+      xfl[j] = ring + wrap(fslot + j) * C::X_BYTES + ((hh * C::HR + ws * MT) * C::HC + r) * 16;
+    // k-step k = (tap_local, st): a PD-deep register pipeline -- the fragments of step k+PD-1 are read
+    // from LDS while the MFMAs of step k run, so the wait in front of a step never covers reads that
+    // were issued just before it (counted lgkmcnt, not lgkmcnt(0)).
+    constexpr int PD = (WS * WN == 4 || TT * MT * NT * 16 + 3 * (NT + TT * MT) * 4 <= 192) ? 3 : 2;  // registers
+    constexpr int KS = 2 * TPS;
+    constexpr int PPS = (NPIECE + KS - 1) / KS;  // DMA pieces per k-step
+    u32x4 bv[PD][NT], av[PD][TT][MT];
     auto load = [&](int k, int buf) {
 #ifdef SFVOS_ABLATE  // timing-only builds (scratch): 1 = no A re-reads, 2 = no B re-reads, 3 = neither
       const bool skip_a = (SFVOS_ABLATE & 1) && k > 1, skip_b = (SFVOS_ABLATE & 2) && k > 1;
@@ -164,52 +218,83 @@ __global__ __launch_bounds__(64 * WS * WN) void conv3d_kernel(ConvArgs a) {
       const int dh = (TAPS == 9) ? tap / 3 : 0, dw = (TAPS == 9) ? tap - 3 * dh : 0;
 #pragma unroll
       for (int q = 0; q < NT; ++q)
-        if (!skip_b) bv[buf][q] = lds_read16(wb + (((tp * 4 + 2 * st + hh) * C::BN) + (wn * NT + q) * 32 + r) * 16);
+        if (!skip_b) bv[buf][q] = lds_read16(wbl + ((tp * 4 + 2 * st) * C::BN + q * 32) * 16);
 #pragma unroll
       for (int j = 0; j < TT; ++j)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
           if (!skip_a)
-            av[buf][j][i] = lds_read16(xf[j] + (((2 * st + hh) * C::HR + ws * MT + i + dh) * C::HC + r + dw) * 16);
+            av[buf][j][i] = lds_read16(xfl[j] + ((2 * st * C::HR + i + dh) * C::HC + dw) * 16);
     };
-    load(0, 0);
 #pragma unroll
-    for (int k = 0; k < 2 * TPS; ++k) {
-      if (k + 1 < 2 * TPS) load(k + 1, (k + 1) & 1);
-      // pin the order: hipcc otherwise sinks each ds_read next to its MFMA and drains lgkmcnt(0)
-      // before every MFMA (LDS-latency-bound stream)
+    for (int k = 0; k < PD - 1 && k < KS; ++k) load(k, k % PD);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      if (k + PD - 1 < KS) load(k + PD - 1, (k + PD - 1) % PD);
+      // pin the order on both sides: hipcc otherwise sinks each ds_read next to its MFMA and drains
+      // lgkmcnt(0) before every MFMA (LDS-latency-bound stream)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < TT; ++j)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int q = 0; q < NT; ++q) Mma<DT>::run(acc[j][i][q], av[k & 1][j][i], bv[k & 1][q]);
+          for (int q = 0; q < NT; ++q) Mma<DT>::run(acc[j][i][q], av[k % PD][j][i], bv[k % PD][q]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < PPS; ++u)
+        if (k * PPS + u < NPIECE) piece(d, k * PPS + u);
     }
   };
 
   // ---- main loop -------------------------------------------------------------------------------------
+  // Temporal taps that can touch a real frame for this frame block: with temporal zero padding
+  // (data-gradient convs, pad_t = kt-1) most (dt, frame) pairs of a block are padding -- skip them.
+  const int dt_lo = max(0, a.pad_t - tb0 - (TT - 1));
+  const int dt_hi = min(a.kt - 1, a.pad_t - tb0 + a.t_in - 1);
+  const int S = ncc * max(0, dt_hi - dt_lo + 1) * C::NTG;
   int s = 0;
-  for (int cc = 0; cc < ncc; ++cc) {
-    // chunk prologue: refill the ring with frames 0..TT-1 of this chunk.  All waves must have
+  // The second-dispatched half of the workgroup loses VALU/LDS issue arbitration to its older SIMD
+  // partner on every stage (stamps: it finishes its MFMAs ~30 % later and the older half then idles
+  // at the barrier); one static priority raise evens them out.
+  if (C::NWAVES == 8 && wv >= 4 && !(a.debug & 32)) __builtin_amdgcn_s_setprio(1);
+  for (int cc = 0; cc < ncc && S > 0; ++cc) {
+    // chunk prologue: refill the ring with the first TT frames of this chunk.  All waves must have
     // finished the previous chunk's last stage before its live slots are overwritten.
     if (cc > 0) __syncthreads();
-    for (int i = 0; i < TT; ++i) issue_frame(cc, i);
-    if (cc == 0) issue_w(0, 0, 0, 0);
-    for (int dt = 0; dt < a.kt; ++dt) {
+    int fslot = (cc * NF + dt_lo) % C::R;  // ring slot of frame dt (the j = 0 frame of the stage)
+    for (int i = 0; i < TT; ++i) {
+      Dma d; d.do_w = false;
+      prep_frame(d, cc, dt_lo + i, wrap(fslot + i));
+      issue_all(d);
+    }
+    if (cc == 0) {
+      Dma d; d.do_x = false;
+      prep_w(d, 0, dt_lo, 0, 0);
+      issue_all(d);
+    }
+    for (int dt = dt_lo; dt <= dt_hi; ++dt) {
       for (int tg = 0; tg < C::NTG; ++tg, ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // stage s operands landed; everyone is done with stage s-1
+        SFVOS_STAMP_AT(3)
+        if (!(a.debug & 16)) __syncthreads();  // stage s operands landed; everyone is done with stage s-1
+        SFVOS_STAMP_AT(0)
+        Dma d; d.do_x = d.do_w = false;
         if (!(a.debug & 2)) {
-          if (tg == 0 && dt + TT < NF) issue_frame(cc, dt + TT);  // slot freed by frame dt-1
-          if (s + 1 < S) {
+          // next frame goes into the slot freed by frame dt-1; next stage's weights into the other buffer
+          if (tg == 0 && dt < dt_hi && !(a.debug & 4)) prep_frame(d, cc, dt + TT, wrap(fslot + TT));
+          if (s + 1 < S && !(a.debug & 8)) {
             int ntg = tg + 1, ndt = dt, ncc2 = cc;
-            if (ntg == C::NTG) { ntg = 0; if (++ndt == a.kt) { ndt = 0; ++ncc2; } }
-            issue_w(ncc2, ndt, ntg, s + 1);
+            if (ntg == C::NTG) { ntg = 0; if (++ndt > dt_hi) { ndt = dt_lo; ++ncc2; } }
+            prep_w(d, ncc2, ndt, ntg, s + 1);
           }
         }
-        if (!(a.debug & 1)) compute(cc, dt, tg, s);
+        SFVOS_STAMP_AT(1)
+        if (!(a.debug & 1)) compute(tg, s, fslot, d);
+        else issue_all(d);
+        SFVOS_STAMP_AT(2)
       }
+      fslot = wrap(fslot + 1);
     }
   }
 
@@ -306,14 +391,20 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
   p->t_out = d->t_in + 2 * d->pad_t - d->kt + 1;
   SFVOS_REQUIRE(p->t_out >= 1, "conv: kernel longer than padded input (t_in %d, kt %d, pad_t %d)", d->t_in, d->kt,
                 d->pad_t);
+#ifdef SFVOS_CONV_4WAVES
+  constexpr int WNW = 1;  // waves across the channel dimension
+#else
+  constexpr int WNW = 2;
+#endif
   if (d->c_out <= 32) {
     p->family = 0; p->TT = pick_tt(p->t_out, 4); p->NT = 1; p->TH = 8; p->BN = 32;
   } else if (d->c_out == 64 && d->taps == 1) {
-    p->family = 1; p->TT = pick_tt(p->t_out, 3); p->NT = 1; p->TH = 8; p->BN = 64;
+    p->family = 1; p->TT = pick_tt(p->t_out, 3); p->NT = 2 / WNW; p->TH = 8; p->BN = 64;
   } else {
-    // 12 accumulator tiles (NT 4 x TT 3) would spill: cap TT at 2 for the 256-wide image
-    p->family = 2; p->NT = d->c_out <= 192 ? 3 : 4; p->TT = pick_tt(p->t_out, p->NT == 4 ? 2 : 3); p->TH = 4;
-    p->BN = 64 * p->NT;
+    // accumulators: TT x NT tiles of 16 registers per wave: at most 16 tiles per wave
+    p->family = 2; p->NT = (d->c_out <= 192 ? 6 : 8) / WNW; p->TT = pick_tt(p->t_out, p->NT == 3 ? 3 : 2);
+    p->TH = 4;
+    p->BN = 32 * p->NT * WNW;
   }
   p->t_blocks = ceil_div(p->t_out, p->TT);
   p->n_blocks = ceil_div(d->c_out, p->BN);
@@ -324,13 +415,17 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
     const bool live = l < lv.n;
     const int H = live ? d->pyr.h[l] : 1, W = live ? d->pyr.w[l] : 1;
     SFVOS_REQUIRE(H >= 1 && W >= 1, "conv: level %d has bad extent %dx%d", l, H, W);
+    SFVOS_REQUIRE((long long)H * W * d->ld_x * (16 / ce) < (1ll << 31),
+                  "conv: level %d frame of %dx%d x pitch %d exceeds the 2 GiB per-frame offset range", l, H, W,
+                  d->ld_x);
     lv.H[l] = H; lv.W[l] = W;
     lv.tiles_h[l] = ceil_div(H, p->TH); lv.tiles_w[l] = ceil_div(W, 32);
     lv.wg_begin[l] = (int)wg; lv.row_begin[l] = (int)rows;
     lv.xpos[l] = (long long)d->batch * d->t_alloc * px;
     lv.ypos[l] = (long long)d->batch * p->t_out * px;
     if (live) {
-      wg += (long long)d->batch * p->t_blocks * p->n_blocks * lv.tiles_h[l] * lv.tiles_w[l];
+      // pixel tiles padded to groups of 8 (XCD-aware order in the kernel)
+      wg += (long long)d->batch * p->n_blocks * ceil_div(lv.tiles_h[l] * lv.tiles_w[l], 8) * 8 * p->t_blocks;
       rows += (long long)d->batch * p->t_blocks * lv.tiles_h[l] * lv.tiles_w[l];
       px += (long long)H * W;
     }
@@ -362,8 +457,19 @@ template <int DT, int TAPS>
 static int dispatch(const ConvPlan& p, const ConvArgs& a, long long grid, hipStream_t s) {
 #define SFVOS_CASE(F, TPSv, TTv, MTv, NTv, WSv, WNv) \
   if (p.family == F && p.TT == TTv && p.NT == NTv) return launch<DT, TAPS, TPSv, TTv, MTv, NTv, WSv, WNv>(a, grid, s);
-  // narrow: 8 rows x 32 px x TT frames x 32 channels; wave = one row, all frames
   constexpr int NTPS = TAPS == 9 ? 9 : 1;
+#ifdef SFVOS_CONV_4WAVES
+  // one wave per SIMD: narrow wave = two rows, all frames; wide wave = one row, all channels
+  SFVOS_CASE(0, NTPS, 1, 2, 1, 4, 1) SFVOS_CASE(0, NTPS, 2, 2, 1, 4, 1) SFVOS_CASE(0, NTPS, 3, 2, 1, 4, 1)
+  SFVOS_CASE(0, NTPS, 4, 2, 1, 4, 1)
+  if constexpr (TAPS == 1) {
+    SFVOS_CASE(1, 1, 1, 2, 2, 4, 1) SFVOS_CASE(1, 1, 2, 2, 2, 4, 1) SFVOS_CASE(1, 1, 3, 2, 2, 4, 1)
+  } else {
+    SFVOS_CASE(2, 3, 1, 1, 6, 4, 1) SFVOS_CASE(2, 3, 2, 1, 6, 4, 1)
+    SFVOS_CASE(2, 3, 1, 1, 8, 4, 1) SFVOS_CASE(2, 3, 2, 1, 8, 4, 1)
+  }
+#else
+  // two waves per SIMD.  narrow: 8 rows x 32 px x TT frames x 32 channels; wave = one row, all frames
   SFVOS_CASE(0, NTPS, 1, 1, 1, 8, 1) SFVOS_CASE(0, NTPS, 2, 1, 1, 8, 1) SFVOS_CASE(0, NTPS, 3, 1, 1, 8, 1)
   SFVOS_CASE(0, NTPS, 4, 1, 1, 8, 1)
   if constexpr (TAPS == 1) {
@@ -374,6 +480,7 @@ static int dispatch(const ConvPlan& p, const ConvArgs& a, long long grid, hipStr
     SFVOS_CASE(2, 3, 1, 1, 3, 4, 2) SFVOS_CASE(2, 3, 2, 1, 3, 4, 2) SFVOS_CASE(2, 3, 3, 1, 3, 4, 2)
     SFVOS_CASE(2, 3, 1, 1, 4, 4, 2) SFVOS_CASE(2, 3, 2, 1, 4, 4, 2)
   }
+#endif
 #undef SFVOS_CASE
   set_error("conv: no kernel instance for family %d TT %d NT %d taps %d", p.family, p.TT, p.NT, TAPS);
   return SFVOS_E_ARG;
@@ -407,6 +514,9 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
   a.t_blocks = p.t_blocks; a.n_blocks = p.n_blocks;
   a.lv = p.lv;
   { const char* dbg = getenv("SFVOS_CONV_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
+#ifdef SFVOS_STAMP
+  { const char* sp = getenv("SFVOS_STAMP_PTR"); a.stamps = sp ? (unsigned long long*)strtoull(sp, nullptr, 0) : nullptr; }
+#endif
   const long long grid = p.lv.wg_begin[SFVOS_MAX_LEVELS];
   SFVOS_REQUIRE(grid > 0, "conv: empty grid");
   hipStream_t s = (hipStream_t)stream;

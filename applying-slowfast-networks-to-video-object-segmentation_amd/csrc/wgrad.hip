@@ -159,13 +159,14 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
       constexpr int TROWS = TAPS == 9 ? 3 : 1, TCOLS = TAPS == 9 ? 3 : 1;
       // step = (ty, dh): one A fragment per ty, TCOLS B fragments per step; the next step's
       // fragments are read while this step's MFMAs run (order pinned with sched_barrier)
-      u32x2 ar[2][2], br[2][TCOLS][2];
+      constexpr int PD = 3, NSTEP = TH * TROWS;
+      u32x2 ar[PD][2], br[PD][TCOLS][2];
       auto load = [&](int step, int buf) {
         const int ty = step / TROWS, dh = step % TROWS;
         if (dh == 0) {
           const char* ap = dyb + ty * 16 * C::ROWB + lane_off;
-          ar[ty & 1][0] = tr_read(ap);
-          ar[ty & 1][1] = tr_read(ap + 4 * C::ROWB);
+          ar[ty % PD][0] = tr_read(ap);
+          ar[ty % PD][1] = tr_read(ap + 4 * C::ROWB);
         }
 #pragma unroll
         for (int dw = 0; dw < TCOLS; ++dw) {
@@ -174,16 +175,17 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
           br[buf][dw][1] = tr_read(bp + 4 * C::ROWB);
         }
       };
-      load(0, 0);
 #pragma unroll
-      for (int step = 0; step < TH * TROWS; ++step) {
-        if (step + 1 < TH * TROWS) load(step + 1, (step + 1) & 1);
+      for (int step = 0; step < PD - 1 && step < NSTEP; ++step) load(step, step % PD);
+#pragma unroll
+      for (int step = 0; step < NSTEP; ++step) {
+        if (step + PD - 1 < NSTEP) load(step + PD - 1, (step + PD - 1) % PD);
         __builtin_amdgcn_sched_barrier(0);
         const int ty = step / TROWS, dh = step % TROWS;
-        const u32x4 av = join(ar[ty & 1][0], ar[ty & 1][1]);
+        const u32x4 av = join(ar[ty % PD][0], ar[ty % PD][1]);
 #pragma unroll
         for (int dw = 0; dw < TCOLS; ++dw)
-          Mma<SFVOS_BF16>::run(acc[dh * TCOLS + dw], av, join(br[step & 1][dw][0], br[step & 1][dw][1]));
+          Mma<SFVOS_BF16>::run(acc[dh * TCOLS + dw], av, join(br[step % PD][dw][0], br[step % PD][dw][1]));
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
