@@ -81,11 +81,14 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
   const int nt = wv % NTN, ct = (wv / NTN) % NTC, dg = wv / (NTN * NTC);
   const int r = lane & 31, hh = lane >> 5;
 
-  int bid = blockIdx.x;
-  const int ps = bid % a.psplit; bid /= a.psplit;
-  const int nb = bid % a.n_blocks; bid /= a.n_blocks;
-  const int cb = bid % a.c_blocks; bid /= a.c_blocks;
-  const int db = bid;
+  // XCD-aware order (speed only): the dt_blocks * n_blocks workgroups that sweep the SAME pixel tiles of
+  // the same c-block (they read the same x tiles) get ids equal mod 8 and adjacent in time.
+  const int G = a.dt_blocks * a.n_blocks, psg_n = (a.psplit + 7) >> 3;
+  int q = blockIdx.x >> 3;
+  const int ps = (q / G % psg_n) * 8 + (blockIdx.x & 7);
+  if (ps >= a.psplit) return;  // padding workgroup
+  const int g = q % G; q /= G * psg_n;
+  const int cb = q, nb = g % a.n_blocks, db = g / a.n_blocks;
   const int n_base = nb * NTN * 32, c_base = cb * NTC * 32, dt0 = db * DG;
   const int dt_live = min(DG, a.kt - dt0);      // temporal taps of this group that exist
   const int nfr = a.t_out + dt_live - 1;        // input frames per tile: t = dt0 .. dt0 + nfr - 1
@@ -103,9 +106,15 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
 
   const bool wave_live = (n_base + nt * 32 < a.c_out) && (c_base + ct * 32 < a.c_in) && (dg < dt_live);
 
-  // stage s -> (tile, frame index fi); DMA of x[t = dt0 + fi] halo tile and dy frame fi
-  auto issue = [&](int s) {
-    const int tile = tile_begin + s / nfr, fi = s % nfr;
+  // ---- DMA side: per-tile context (recomputed only when the issued stage enters a new pixel tile) ---
+  constexpr int NDY = (C::DY_SLOTS + 511) / 512, NXP = (C::X_SLOTS + 511) / 512, NPIECE = NDY + NXP;
+  int dyo[NDY], xo[NXP];  // byte offsets inside a frame; -1 zero page; -2 no slot
+  const char* dy_tile = a.dy;  // frame 0 of the tile's clip in dy / frame dt0 in x
+  const char* x_tile = a.x;
+  long long dy_fstride = 0, x_fstride = 0;
+  int i_tile = -1, i_fi = 0;  // tile / frame index of the NEXT stage to issue
+  const int lds_wave_off = wv * 1024;
+  auto enter_tile = [&](int tile) {
     int lvl = 0;
 #pragma unroll
     for (int l = 1; l < SFVOS_MAX_LEVELS; ++l)
@@ -117,62 +126,87 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
     const int th = k % a.lv.tiles_h[lvl]; k /= a.lv.tiles_h[lvl];
     const int b = k;
     const int h0 = th * TH, w0 = tw * 16;
-    const int t = dt0 + fi;
-    char* xb = xbase + (s & 1) * C::X_BYTES;
-    char* dyb = dybase + (s % C::R) * C::DY_BYTES;
-    const bool dy_ok = fi < a.t_out;
-    const char* dyf = a.dy + (a.lv.ypos[lvl] + ((long long)b * a.t_out + fi) * HWp) * a.ld_y * ES;
+    dy_fstride = HWp * a.ld_y * ES;
+    x_fstride = HWp * a.ld_x * ES;
+    dy_tile = a.dy + (a.lv.ypos[lvl] + (long long)b * a.t_out * HWp) * a.ld_y * ES;
+    x_tile = a.x + (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset + dt0) * HWp) * a.ld_x * ES;
 #pragma unroll
-    for (int it = 0; it < (C::DY_SLOTS + 511) / 512; ++it) {
+    for (int it = 0; it < NDY; ++it) {
       const int sl = it * 512 + tid;
-      if (sl < C::DY_SLOTS) {
-        const int j = sl % C::SPP, pos = (sl / C::SPP) % C::NPOS, tnt = sl / (C::SPP * C::NPOS);
-        const int h = h0 + pos / 16, w = w0 + pos % 16, n = n_base + tnt * 32;
-        const bool ok = dy_ok && h < H && w < W && n < a.c_out;
-        const char* src = ok ? dyf + ((long long)(h * W + w) * a.ld_y + n + j * CE) * ES : a.zeros;
-        glds16(src, dyb + (sl - lane) * 16);
-      }
+      const int j = sl % C::SPP, pos = (sl / C::SPP) % C::NPOS, tnt = sl / (C::SPP * C::NPOS);
+      const int h = h0 + pos / 16, w = w0 + pos % 16, n = n_base + tnt * 32;
+      const bool ok = h < H && w < W && n < a.c_out;
+      dyo[it] = sl >= C::DY_SLOTS ? -2 : (ok ? (int)((((long long)h * W + w) * a.ld_y + n + j * CE) * ES) : -1);
     }
-    const bool x_ok = t < a.t_in;
-    const char* xf = a.x + (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset + t) * HWp) * a.ld_x * ES;
 #pragma unroll
-    for (int it = 0; it < (C::X_SLOTS + 511) / 512; ++it) {
+    for (int it = 0; it < NXP; ++it) {
       const int sl = it * 512 + tid;
-      if (sl < C::X_SLOTS) {
-        const int j = sl % C::SPP, hp = (sl / C::SPP) % C::NHPOS, tct = sl / (C::SPP * C::NHPOS);
-        const int h = h0 + hp / C::HC - C::HALO, w = w0 + hp % C::HC - C::HALO, c = c_base + tct * 32;
-        const bool ok = x_ok && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W && c < a.c_in;
-        const char* src = ok ? xf + ((long long)(h * W + w) * a.ld_x + c + j * CE) * ES : a.zeros;
-        glds16(src, xb + (sl - lane) * 16);
-      }
+      const int j = sl % C::SPP, hp = (sl / C::SPP) % C::NHPOS, tct = sl / (C::SPP * C::NHPOS);
+      const int h = h0 + hp / C::HC - C::HALO, w = w0 + hp % C::HC - C::HALO, c = c_base + tct * 32;
+      const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W && c < a.c_in;
+      xo[it] = sl >= C::X_SLOTS ? -2 : (ok ? (int)((((long long)h * W + w) * a.ld_x + c + j * CE) * ES) : -1);
+    }
+  };
+  // scalars of the copy for stage s (x[t = dt0 + fi] halo tile -> x buffer s&1, dy frame fi -> ring slot s%R)
+  struct Dma { const char* dyf; const char* xf; char* dyb; char* xb; bool on, dy_ok, x_ok; };
+  auto prep = [&](Dma& d, int s) {
+    if (i_tile < 0 || i_fi == nfr) {
+      i_tile = i_tile < 0 ? tile_begin : i_tile + 1;
+      i_fi = 0;
+      enter_tile(i_tile);
+    }
+    d.on = true;
+    d.dy_ok = i_fi < a.t_out;
+    d.x_ok = dt0 + i_fi < a.t_in;
+    d.dyf = dy_tile + (long long)i_fi * dy_fstride;
+    d.xf = x_tile + (long long)i_fi * x_fstride;
+    d.xb = xbase + (s & 1) * C::X_BYTES + lds_wave_off;
+    d.dyb = dybase + (s % C::R) * C::DY_BYTES + lds_wave_off;
+    ++i_fi;
+  };
+  auto piece = [&](const Dma& d, int p) {
+    if (!d.on) return;
+    if (p < NDY) {
+      if (dyo[p] > -2) glds16((d.dy_ok && dyo[p] >= 0) ? d.dyf + dyo[p] : a.zeros, d.dyb + p * 8192);
+    } else {
+      const int u = p - NDY;
+      if (xo[u] > -2) glds16((d.x_ok && xo[u] >= 0) ? d.xf + xo[u] : a.zeros, d.xb + u * 8192);
     }
   };
 
-  auto compute = [&](int s) {
+  // ---- compute side --------------------------------------------------------------------------------
+  auto compute = [&](int s, bool live, const Dma& d) {
     // this wave pairs x[t] with dy[t - dt0 - dg], which entered the ring dg stages ago
     const char* dyb = dybase + ((s - dg + C::R) % C::R) * C::DY_BYTES + nt * (C::NPOS * C::ROWB);
     const char* xb = xbase + (s & 1) * C::X_BYTES + ct * (C::NHPOS * C::ROWB);
+    if (!live) {  // nothing to multiply at this stage (frame outside this wave's tap): just feed the DMA
+#pragma unroll
+      for (int p = 0; p < NPIECE; ++p) piece(d, p);
+      return;
+    }
     if constexpr (DT == SFVOS_BF16) {
       // lane -> (row q, 4-column group p) of its 16-lane group's 4x16 block; block rows k0..k0+3
-      const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-      const int lane_off = (8 * (g >> 1) + q) * C::ROWB + (16 * (g & 1) + 4 * p) * 2;
+      const int gq = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
+      const int lane_off = (8 * (gq >> 1) + qq) * C::ROWB + (16 * (gq & 1) + 4 * pp) * 2;
+      const char* dyl = dyb + lane_off;  // every read below adds a compile-time constant (ds_read offset field)
+      const char* xl = xb + lane_off;
       constexpr int TROWS = TAPS == 9 ? 3 : 1, TCOLS = TAPS == 9 ? 3 : 1;
-      // step = (ty, dh): one A fragment per ty, TCOLS B fragments per step; the next step's
-      // fragments are read while this step's MFMAs run (order pinned with sched_barrier)
+      // step = (ty, dh): one A fragment per ty, TCOLS B fragments per step; a PD-deep register pipeline
+      // reads the fragments of step+PD-1 while this step's MFMAs run (order pinned with sched_barrier);
+      // the DMA pieces of the next stage are issued between the MFMA groups.
       constexpr int PD = 3, NSTEP = TH * TROWS;
+      constexpr int PPS = (NPIECE + NSTEP - 1) / NSTEP;
       u32x2 ar[PD][2], br[PD][TCOLS][2];
       auto load = [&](int step, int buf) {
         const int ty = step / TROWS, dh = step % TROWS;
         if (dh == 0) {
-          const char* ap = dyb + ty * 16 * C::ROWB + lane_off;
-          ar[ty % PD][0] = tr_read(ap);
-          ar[ty % PD][1] = tr_read(ap + 4 * C::ROWB);
+          ar[ty % PD][0] = tr_read(dyl + ty * 16 * C::ROWB);
+          ar[ty % PD][1] = tr_read(dyl + (ty * 16 + 4) * C::ROWB);
         }
 #pragma unroll
         for (int dw = 0; dw < TCOLS; ++dw) {
-          const char* bp = xb + ((ty + dh) * C::HC + dw) * C::ROWB + lane_off;
-          br[buf][dw][0] = tr_read(bp);
-          br[buf][dw][1] = tr_read(bp + 4 * C::ROWB);
+          br[buf][dw][0] = tr_read(xl + ((ty + dh) * C::HC + dw) * C::ROWB);
+          br[buf][dw][1] = tr_read(xl + ((ty + dh) * C::HC + dw + 4) * C::ROWB);
         }
       };
 #pragma unroll
@@ -187,8 +221,13 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
         for (int dw = 0; dw < TCOLS; ++dw)
           Mma<SFVOS_BF16>::run(acc[dh * TCOLS + dw], av, join(br[step % PD][dw][0], br[step % PD][dw][1]));
         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < PPS; ++u)
+          if (step * PPS + u < NPIECE) piece(d, step * PPS + u);
       }
     } else {
+#pragma unroll
+      for (int p = 0; p < NPIECE; ++p) piece(d, p);
 #pragma unroll
       for (int ty = 0; ty < TH; ++ty) {
 #pragma unroll
@@ -205,13 +244,21 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
     }
   };
 
-  if (S > 0) issue(0);
+  if (S > 0) {
+    Dma d0;
+    prep(d0, 0);
+#pragma unroll
+    for (int p = 0; p < NPIECE; ++p) piece(d0, p);
+  }
+  int c_fi = 0;  // frame index of the stage being computed
   for (int s = 0; s < S; ++s) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (s + 1 < S) issue(s + 1);
-    const int fo = s % nfr - dg;  // dy frame this wave pairs with x[t] at this stage
-    if (wave_live && fo >= 0 && fo < a.t_out) compute(s);
+    Dma d; d.on = false;
+    if (s + 1 < S) prep(d, s + 1);
+    const int fo = c_fi - dg;  // dy frame this wave pairs with x[t] at this stage
+    compute(s, wave_live && fo >= 0 && fo < a.t_out, d);
+    if (++c_fi == nfr) c_fi = 0;
   }
 
   // slab[ps][n][dt][tap][c]
@@ -356,7 +403,8 @@ extern "C" int sfvos_conv3d_wgrad(const sfvos_conv_desc* d, const void* x, const
   a.n_blocks = p.n_blocks; a.c_blocks = p.c_blocks;
   a.dt_blocks = p.dt_blocks; a.psplit = p.psplit;
   a.ntiles = p.ntiles; a.lv = p.lv;
-  const long long grid = (long long)p.psplit * p.n_blocks * p.c_blocks * p.dt_blocks;
+  // psplit padded to a multiple of 8 (XCD-aware order in the kernel; padding workgroups exit at once)
+  const long long grid = (long long)ceil_div(p.psplit, 8) * 8 * p.n_blocks * p.c_blocks * p.dt_blocks;
   hipStream_t s = (hipStream_t)stream;
   const bool bf = d->dtype == SFVOS_BF16;
   switch (p.cfg) {

@@ -12,7 +12,8 @@ import-time side effects).
 
 What is stored per case (fp32 unless noted), all from the reference class:
   out/<clip>/<level>       fused feature map [1,256,H,W] (clip 0 only for big cases)
-  loss/<clip>              proxy loss  sum_levels mean(out^2)
+  clips, relu_margins      closed-form clip ids chosen for their ReLU margin (see relu_margin) and the margins
+  loss/<clip>              proxy loss  sum_levels mean((out - target)^2)   (oracle.slowfast_ref.proxy_loss)
   stat/<key>               every BN running_mean / running_var / num_batches_tracked
                            after the two training clips
   gnorm/<key>, gsamp/<key> L2 norm and 64 strided samples of each parameter's grad
@@ -64,22 +65,54 @@ def sample_idx(numel):
     return (np.arange(NSAMP, dtype=np.int64) * 7919) % numel
 
 
-def clip_inputs(sp, fp, levels, clip):
-    zero = (0,) if (clip == 1 and fp > 1) else ()
-    fast = closed_form_features(fp, levels, clip=clip, zero_frames=zero)
+def clip_inputs(sp, fp, levels, clip_id, zero_first):
+    zero = (0,) if zero_first else ()
+    fast = closed_form_features(fp, levels, clip=clip_id, zero_frames=zero)
     return [slice_slow(fast, sp)], [fast]
+
+
+def relu_margin(model, sp, fp, levels, clip_id, zero_first):
+    """min |pre-activation| over every ReLU input of one training forward.  A ReLU whose input sits within
+    fp32 round-off of 0 makes the backward discontinuous: two correct implementations (or the reference at
+    another thread count) disagree by O(1e-2) in a few gradient entries.  Fixture clips are chosen with a
+    margin far above round-off so that a 1e-3 gradient tolerance is meaningful."""
+    margins = []
+    hook = model.relu.register_forward_pre_hook(lambda m, inp: margins.append(float(inp[0].detach().abs().min())))
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    model.train()
+    with torch.no_grad():
+        slow, fast = clip_inputs(sp, fp, levels, clip_id, zero_first)
+        model.temporally_enhance_features(slow, fast)
+    hook.remove()
+    model.load_state_dict(state)   # undo the running-stat update
+    return min(margins)
+
+
+def pick_clips(cls, sp, fp, levels, candidates=300):
+    model = cls(256, torch.device('cpu'), sp, fp)
+    model.load_state_dict(closed_form_state_dict(model))
+    scored = []
+    for cid in range(candidates):
+        zero_first = (cid % 2 == 1) and fp > 1     # odd candidates mimic end-of-sequence zero padding
+        scored.append((relu_margin(model, sp, fp, levels, cid, zero_first), cid))
+    best_plain = max(m for m in scored if m[1] % 2 == 0)
+    best_zero = max(m for m in scored if m[1] % 2 == 1)
+    return [best_plain[1], best_zero[1]], [best_plain[0], best_zero[0]]
 
 
 def run_case(cls, sp, fp, levels, tag, store_all_clips):
     torch.manual_seed(0)
+    clips, margins = pick_clips(cls, sp, fp, levels)
+    print('  (%d,%d) %s: clips %s relu margins %s' % (sp, fp, tag, clips, ['%.1e' % m for m in margins]), flush=True)
+    assert min(margins) > 3e-6, "no clip with a safe ReLU margin found (fp32 round-off is ~5e-7 here)"
     model = cls(256, torch.device('cpu'), sp, fp)
     model.load_state_dict(closed_form_state_dict(model))
-    rec = {}
+    rec = {'clips': np.array(clips, dtype=np.int64), 'relu_margins': np.array(margins, dtype=np.float32)}
 
     # eval mode first (does not touch running stats)
     model.eval()
     with torch.no_grad():
-        slow, fast = clip_inputs(sp, fp, levels, 0)
+        slow, fast = clip_inputs(sp, fp, levels, clips[0], False)
         out = model.temporally_enhance_features(slow, fast)
     for k, v in out.items():
         rec['eval_out/%s' % k] = v.numpy().copy()
@@ -90,7 +123,7 @@ def run_case(cls, sp, fp, levels, tag, store_all_clips):
     opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=1e-4)
     opt.zero_grad()
     for clip in (0, 1):
-        slow, fast = clip_inputs(sp, fp, levels, clip)
+        slow, fast = clip_inputs(sp, fp, levels, clips[clip], clip == 1 and fp > 1)
         out = model.temporally_enhance_features(slow, fast)
         loss = proxy_loss(out)
         loss.backward()
@@ -117,15 +150,16 @@ def run_case(cls, sp, fp, levels, tag, store_all_clips):
 def input_grad_case(cls, sp, fp, levels):
     """OSVOS-with-trainable-backbone needs dgrad into the inputs
     (reference code/osvos/osvos_model.py:50,64): pin it for one config."""
+    clips, margins = pick_clips(cls, sp, fp, levels)
     model = cls(256, torch.device('cpu'), sp, fp)
     model.load_state_dict(closed_form_state_dict(model))
     model.train()
-    fast = closed_form_features(fp, levels, clip=0)
+    fast = closed_form_features(fp, levels, clip=clips[0])
     for v in fast.values():
         v.requires_grad_(True)
     out = model.temporally_enhance_features([slice_slow(fast, sp)], [fast])
     proxy_loss(out).backward()
-    rec = {}
+    rec = {'clips': np.array(clips, dtype=np.int64)}
     for k, v in fast.items():
         g = v.grad.reshape(-1)
         rec['ignorm/%s' % k] = np.float32(g.double().norm().item())

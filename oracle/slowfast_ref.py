@@ -100,10 +100,17 @@ class OracleSlowFastLayers(nn.Module):
 
 def proxy_loss(merged):
     """Stand-in for the RoI-head losses (torchvision, absent): sum over levels of
-    mean(out**2).  Defined by SURVEY.md 8c/8d, not by the reference."""
+    mean((out - target)**2) with a fixed closed-form target per level.
+
+    SURVEY.md 8c/8d proposed sum_l mean(out_l**2); with train-mode BatchNorm as the last op of both
+    pathways that functional is (numerically) constant in everything upstream -- its conv-weight
+    gradients are pure round-off -- so it cannot pin a backward pass.  The target makes the gradient
+    of every parameter O(1e-3) and well conditioned.  Defined by this build, not by the reference."""
+    from oracle.closed_form import closed_form_tensor
     total = None
-    for v in merged.values():
-        term = (v.float() ** 2).mean()
+    for k, v in merged.items():
+        tgt = closed_form_tensor(tuple(v.shape), 'target/%s' % k, 4.0).to(v.device)
+        term = ((v.float() - tgt) ** 2).mean()
         total = term if total is None else total + term
     return total
 

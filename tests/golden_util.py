@@ -30,9 +30,12 @@ def sample_idx(numel):
     return (np.arange(NSAMP, dtype=np.int64) * 7919) % numel
 
 
-def clip_inputs(sp, fp, levels, clip, device=None):
+def clip_inputs(sp, fp, levels, clip, device=None, clips=(0, 1)):
+    """clip = 0/1: first / second accumulated clip of a fixture; `clips` = the fixture's `clips` entry (the
+    closed-form clip ids oracle/make_golden.py picked for their ReLU margin).  The second clip has its
+    first frame zeroed (mimics the reference's zero feature padding at sequence ends)."""
     zero = (0,) if (clip == 1 and fp > 1) else ()
-    fast = closed_form_features(fp, levels, clip=clip, zero_frames=zero)
+    fast = closed_form_features(fp, levels, clip=int(clips[clip]), zero_frames=zero)
     if device is not None:
         fast = OrderedDict((k, v.to(device)) for k, v in fast.items())
     return [slice_slow(fast, sp)], [fast]

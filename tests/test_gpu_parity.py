@@ -35,7 +35,7 @@ def _check_against_fixture(sp, fp, levels, g, use_fused_sgd):
     # ---- eval mode
     m.eval()
     with torch.no_grad():
-        slow, fast = clip_inputs(sp, fp, levels, 0, dev)
+        slow, fast = clip_inputs(sp, fp, levels, 0, dev, clips=g['clips'])
         out = m.temporally_enhance_features(slow, fast)
     assert list(out.keys()) == list(levels.keys())
     for k, v in out.items():
@@ -51,7 +51,7 @@ def _check_against_fixture(sp, fp, levels, g, use_fused_sgd):
         torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=1e-4)
     opt.zero_grad()
     for clip in (0, 1):
-        slow, fast = clip_inputs(sp, fp, levels, clip, dev)
+        slow, fast = clip_inputs(sp, fp, levels, clip, dev, clips=g['clips'])
         out = m.temporally_enhance_features(slow, fast)
         loss = proxy_loss(out)
         loss.backward()
@@ -102,7 +102,7 @@ def test_input_gradient_matches_reference_fixture():
     m, dev = build(3, 7, 'fp32')
     m.train()
     from oracle.closed_form import closed_form_features, slice_slow
-    fast = closed_form_features(7, SMALL_LEVELS, clip=0)
+    fast = closed_form_features(7, SMALL_LEVELS, clip=int(g['clips'][0]))
     fast = OrderedDict((k, v.to(dev).requires_grad_(True)) for k, v in fast.items())
     out = m.temporally_enhance_features([slice_slow(fast, 3)], [fast])
     proxy_loss(out).backward()
@@ -169,7 +169,7 @@ def test_bf16_path_error_is_bounded(sp, fp):
     g = load_case(sp, fp, 'small')
     m, dev = build(sp, fp, 'bf16')
     m.train()
-    slow, fast = clip_inputs(sp, fp, SMALL_LEVELS, 0, dev)
+    slow, fast = clip_inputs(sp, fp, SMALL_LEVELS, 0, dev, clips=g['clips'])
     out = m.temporally_enhance_features(slow, fast)
     loss = proxy_loss(out)
     loss.backward()

@@ -59,7 +59,7 @@ def _run_oracle(sp, fp, levels, g):
     m.load_state_dict(closed_form_state_dict(m))
     m.eval()
     with torch.no_grad():
-        slow, fast = clip_inputs(sp, fp, levels, 0)
+        slow, fast = clip_inputs(sp, fp, levels, 0, clips=g['clips'])
         out = m.temporally_enhance_features(slow, fast)
     for k, v in out.items():
         assert max_rel_err(v.numpy(), g['eval_out/%s' % k]) < TOL
@@ -68,7 +68,7 @@ def _run_oracle(sp, fp, levels, g):
     params = list(m.parameters())
     bufs = [None] * len(params)
     for clip in (0, 1):
-        slow, fast = clip_inputs(sp, fp, levels, clip)
+        slow, fast = clip_inputs(sp, fp, levels, clip, clips=g['clips'])
         out = m.temporally_enhance_features(slow, fast)
         loss = proxy_loss(out)
         loss.backward()
