@@ -55,7 +55,9 @@ struct ConvArgs {
   float* stat_part;
   const char* zeros;
   int batch, t_in, t_alloc, t_offset, t_out, c_in, c_out, kt, pad_t, ld_x, ld_y, accumulate;
-  int t_blocks, n_blocks;
+  int t_blocks, n_blocks;  // frame blocks of THIS launch
+  int t_first, t_end;      // output frames [t_first, t_end) of this launch (a layer may take two launches:
+  int tb_offset, t_blocks_total;  // blocks of TT and of TT-1 frames so that no frame slot is padding)
   int debug;  // timing-only: bit0 skip compute, bit1 skip DMA after the first stage (results wrong)
 #ifdef SFVOS_STAMP
   unsigned long long* stamps;  // diagnostic build only: s_memtime stamps of one workgroup
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(64 * WS * WN, (WS * WN) / 4) void conv3d_kernel(Con
   const int bn = grp / tgroups;
   const int nb = bn % a.n_blocks, b = bn / a.n_blocks;
   const int th = tile / tiles_w, tw = tile - th * tiles_w;
-  const int h0 = th * C::TH, w0 = tw * C::TW, n0 = nb * C::BN, tb0 = tb * TT;
+  const int h0 = th * C::TH, w0 = tw * C::TW, n0 = nb * C::BN, tb0 = a.t_first + tb * TT;
 
   const int NF = TT + a.kt - 1;  // input frames this workgroup touches: t = tb0 - pad_t + i
   const int ncc = a.c_in / CK;
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(64 * WS * WN, (WS * WN) / 4) void conv3d_kernel(Con
 #pragma unroll
     for (int j = 0; j < TT; ++j) {
       const int to = tb0 + j;
-      if (to < a.t_out) {
+      if (to < a.t_end) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           const int h = h0 + ws * MT + i;
@@ -351,7 +353,8 @@ __global__ __launch_bounds__(64 * WS * WN, (WS * WN) / 4) void conv3d_kernel(Con
         t1 += red[(((wn_ * WS + k) * NT + q) * 32 + l) * 2 + 0];
         t2 += red[(((wn_ * WS + k) * NT + q) * 32 + l) * 2 + 1];
       }
-      const long long prow = a.lv.row_begin[lvl] + ((long long)(b * a.t_blocks + tb) * tiles_h + th) * tiles_w + tw;
+      const long long prow = a.lv.row_begin[lvl] +
+                             ((long long)(b * a.t_blocks_total + a.tb_offset + tb) * tiles_h + th) * tiles_w + tw;
       a.stat_part[(prow * 2 + 0) * a.c_out + n0 + tid] = t1;
       a.stat_part[(prow * 2 + 1) * a.c_out + n0 + tid] = t2;
     }
@@ -362,14 +365,26 @@ __global__ __launch_bounds__(64 * WS * WN, (WS * WN) / 4) void conv3d_kernel(Con
 struct ConvPlan {
   int family;  // 0 narrow (c_out <= 32), 1 mid (c_out == 64, 1x1), 2 wide
   int TT, NT, TH, BN;
-  int t_blocks, n_blocks, t_out;
+  int t_blocks, n_blocks, t_out;  // t_blocks = total frame blocks
+  int n_launch, l_tt[2], l_blocks[2], l_first[2];  // launches: blocks of l_tt frames starting at frame l_first
   ConvLevels lv;
 };
 
-static int pick_tt(int t_out, int max_tt) {
-  // fewest frame blocks first, then the smallest TT that covers them
-  const int nblk = ceil_div(t_out, max_tt);
-  return ceil_div(t_out, nblk);
+// Frame blocks: fewest blocks of at most max_tt frames, sizes as even as possible and NO padded frame:
+// rem blocks of base+1 frames (first launch) followed by nblk-rem blocks of base frames (second launch).
+static void split_frames(int t_out, int max_tt, ConvPlan* p);
+
+static void split_frames(int t_out, int max_tt, ConvPlan* p) {
+  const int nblk = ceil_div(t_out, max_tt), base = t_out / nblk, rem = t_out % nblk;
+  p->t_blocks = nblk;
+  p->n_launch = 0;
+  if (rem > 0) {
+    p->l_tt[p->n_launch] = base + 1; p->l_blocks[p->n_launch] = rem; p->l_first[p->n_launch] = 0;
+    ++p->n_launch;
+  }
+  p->l_tt[p->n_launch] = base; p->l_blocks[p->n_launch] = nblk - rem; p->l_first[p->n_launch] = rem * (base + 1);
+  ++p->n_launch;
+  p->TT = p->l_tt[0];
 }
 
 static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
@@ -397,16 +412,15 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
   constexpr int WNW = 2;
 #endif
   if (d->c_out <= 32) {
-    p->family = 0; p->TT = pick_tt(p->t_out, 4); p->NT = 1; p->TH = 8; p->BN = 32;
+    p->family = 0; split_frames(p->t_out, 4, p); p->NT = 1; p->TH = 8; p->BN = 32;
   } else if (d->c_out == 64 && d->taps == 1) {
-    p->family = 1; p->TT = pick_tt(p->t_out, 3); p->NT = 2 / WNW; p->TH = 8; p->BN = 64;
+    p->family = 1; split_frames(p->t_out, 3, p); p->NT = 2 / WNW; p->TH = 8; p->BN = 64;
   } else {
     // accumulators: TT x NT tiles of 16 registers per wave: at most 16 tiles per wave
-    p->family = 2; p->NT = (d->c_out <= 192 ? 6 : 8) / WNW; p->TT = pick_tt(p->t_out, p->NT == 3 ? 3 : 2);
+    p->family = 2; p->NT = (d->c_out <= 192 ? 6 : 8) / WNW; split_frames(p->t_out, p->NT == 3 ? 3 : 2, p);
     p->TH = 4;
     p->BN = 32 * p->NT * WNW;
   }
-  p->t_blocks = ceil_div(p->t_out, p->TT);
   p->n_blocks = ceil_div(d->c_out, p->BN);
   ConvLevels& lv = p->lv;
   lv.n = d->pyr.n_levels;
@@ -425,7 +439,7 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
     lv.ypos[l] = (long long)d->batch * p->t_out * px;
     if (live) {
       // pixel tiles padded to groups of 8 (XCD-aware order in the kernel)
-      wg += (long long)d->batch * p->n_blocks * ceil_div(lv.tiles_h[l] * lv.tiles_w[l], 8) * 8 * p->t_blocks;
+      wg += (long long)d->batch * p->n_blocks * ceil_div(lv.tiles_h[l] * lv.tiles_w[l], 8) * 8;  // x blocks per launch
       rows += (long long)d->batch * p->t_blocks * lv.tiles_h[l] * lv.tiles_w[l];
       px += (long long)H * W;
     }
@@ -511,16 +525,27 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
   a.batch = d->batch; a.t_in = d->t_in; a.t_alloc = d->t_alloc; a.t_offset = d->t_offset; a.t_out = p.t_out;
   a.c_in = d->c_in; a.c_out = d->c_out; a.kt = d->kt;
   a.pad_t = d->pad_t; a.ld_x = d->ld_x; a.ld_y = d->ld_y; a.accumulate = d->accumulate;
-  a.t_blocks = p.t_blocks; a.n_blocks = p.n_blocks;
-  a.lv = p.lv;
+  a.n_blocks = p.n_blocks; a.t_blocks_total = p.t_blocks;
   { const char* dbg = getenv("SFVOS_CONV_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
 #ifdef SFVOS_STAMP
   { const char* sp = getenv("SFVOS_STAMP_PTR"); a.stamps = sp ? (unsigned long long*)strtoull(sp, nullptr, 0) : nullptr; }
 #endif
-  const long long grid = p.lv.wg_begin[SFVOS_MAX_LEVELS];
-  SFVOS_REQUIRE(grid > 0, "conv: empty grid");
   hipStream_t s = (hipStream_t)stream;
-  if (d->dtype == SFVOS_BF16)
-    return d->taps == 9 ? dispatch<SFVOS_BF16, 9>(p, a, grid, s) : dispatch<SFVOS_BF16, 1>(p, a, grid, s);
-  return d->taps == 9 ? dispatch<SFVOS_F32, 9>(p, a, grid, s) : dispatch<SFVOS_F32, 1>(p, a, grid, s);
+  int tb_offset = 0;
+  for (int li = 0; li < p.n_launch; ++li) {
+    p.TT = p.l_tt[li];
+    a.t_blocks = p.l_blocks[li]; a.t_first = p.l_first[li]; a.t_end = a.t_first + p.l_tt[li] * p.l_blocks[li];
+    a.tb_offset = tb_offset;
+    tb_offset += p.l_blocks[li];
+    a.lv = p.lv;  // workgroup prefix of this launch: per-level unit count x its frame blocks
+    for (int l = 0; l <= SFVOS_MAX_LEVELS; ++l) a.lv.wg_begin[l] = p.lv.wg_begin[l] * a.t_blocks;
+    const long long grid = a.lv.wg_begin[SFVOS_MAX_LEVELS];
+    SFVOS_REQUIRE(grid > 0 && grid < (1ll << 31), "conv: grid %lld out of range", grid);
+    if (d->dtype == SFVOS_BF16)
+      rc = d->taps == 9 ? dispatch<SFVOS_BF16, 9>(p, a, grid, s) : dispatch<SFVOS_BF16, 1>(p, a, grid, s);
+    else
+      rc = d->taps == 9 ? dispatch<SFVOS_F32, 9>(p, a, grid, s) : dispatch<SFVOS_F32, 1>(p, a, grid, s);
+    if (rc != SFVOS_OK) return rc;
+  }
+  return SFVOS_OK;
 }

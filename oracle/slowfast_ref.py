@@ -106,13 +106,24 @@ def proxy_loss(merged):
     pathways that functional is (numerically) constant in everything upstream -- its conv-weight
     gradients are pure round-off -- so it cannot pin a backward pass.  The target makes the gradient
     of every parameter O(1e-3) and well conditioned.  Defined by this build, not by the reference."""
-    from oracle.closed_form import closed_form_tensor
     total = None
     for k, v in merged.items():
-        tgt = closed_form_tensor(tuple(v.shape), 'target/%s' % k, 4.0).to(v.device)
+        tgt = _target(k, tuple(v.shape), v.device)
         term = ((v.float() - tgt) ** 2).mean()
         total = term if total is None else total + term
     return total
+
+
+_TARGETS = {}
+
+
+def _target(key, shape, device):
+    """closed-form target of one level, built once per (level, shape, device)."""
+    from oracle.closed_form import closed_form_tensor
+    ck = (key, shape, str(device))
+    if ck not in _TARGETS:
+        _TARGETS[ck] = closed_form_tensor(shape, 'target/%s' % key, 4.0).to(device)
+    return _TARGETS[ck]
 
 
 def proxy_argmax(merged):
