@@ -303,33 +303,58 @@ __global__ __launch_bounds__(64 * WS * WN, (WS * WN) / 4) void conv3d_kernel(Con
   }
 
   // ---- epilogue --------------------------------------------------------------------------------------
+  // Each 32 px x 32 ch accumulator tile goes through a per-wave f32 scratch in LDS (the staging buffers
+  // are dead) and leaves as 16-byte chunks: lane -> (pixel, 8 or 4 channels), so a pixel's 32-channel
+  // segment is written (and, when accumulating, read) as whole 64/128-byte runs instead of 2-byte pieces.
   float s1[NT], s2[NT];
 #pragma unroll
   for (int q = 0; q < NT; ++q) s1[q] = s2[q] = 0.f;
   T* yclip = (T*)a.y + (a.lv.ypos[lvl] + (long long)b * a.t_out * HWp) * a.ld_y;
+  __syncthreads();  // every wave has finished reading the ring / weight buffers
+  float* scr = (float*)smem + wv * (32 * 33);  // [32 px][32 ch], rows padded to 33 floats
+  constexpr int CPP = 32 / CE;                  // 16-byte output chunks per pixel of a tile
 #pragma unroll
   for (int q = 0; q < NT; ++q) {
-    const int n = n0 + (wn * NT + q) * 32 + r;
-    const bool nok = n < a.c_out;
-    const float bias = (a.bias && nok) ? a.bias[n] : 0.f;
+    const int nbase = n0 + (wn * NT + q) * 32;
+    if (nbase >= a.c_out) continue;  // wave-uniform
+    const float bias = a.bias ? a.bias[nbase + r] : 0.f;
 #pragma unroll
     for (int j = 0; j < TT; ++j) {
       const int to = tb0 + j;
-      if (to < a.t_end) {
+      if (to >= a.t_end) continue;  // wave-uniform
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int h = h0 + ws * MT + i;
+      for (int i = 0; i < MT; ++i) {
+        const int h = h0 + ws * MT + i;
+        if (h >= H) continue;  // wave-uniform
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int w = w0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-            if (nok && h < H && w < W) {
-              T* dst = yclip + ((long long)(to * H + h) * W + w) * a.ld_y + n;
-              float v = acc[j][i][q][e] + bias;
-              if (a.accumulate) v += Elt<DT>::to_f32(*dst);
-              *dst = Elt<DT>::from_f32(v);
-              s1[q] += v;
-              s2[q] += v * v;
+        for (int e = 0; e < 16; ++e) {
+          const int px = (e & 3) + 8 * (e >> 2) + 4 * hh;
+          const float v = acc[j][i][q][e] + bias;
+          scr[px * 33 + r] = v;
+          if (w0 + px < W) { s1[q] += v; s2[q] += v * v; }
+        }
+        T* yrow = yclip + ((long long)(to * H + h) * W + w0) * a.ld_y + nbase;
+#pragma unroll
+        for (int it = 0; it < (32 * CPP) / 64; ++it) {
+          const int idx = it * 64 + lane, px = idx / CPP, ch = (idx % CPP) * CE;
+          float f[CE];
+#pragma unroll
+          for (int u = 0; u < CE; ++u) f[u] = scr[px * 33 + ch + u];
+          if (w0 + px < W) {
+            T* dst = yrow + (long long)px * a.ld_y + ch;
+            if (a.accumulate) {
+              const u32x4 old = *(const u32x4*)dst;
+              T oldv[CE];
+              __builtin_memcpy(oldv, &old, 16);
+#pragma unroll
+              for (int u = 0; u < CE; ++u) f[u] += Elt<DT>::to_f32(oldv[u]);
             }
+            T outv[CE];
+#pragma unroll
+            for (int u = 0; u < CE; ++u) outv[u] = Elt<DT>::from_f32(f[u]);
+            u32x4 o;
+            __builtin_memcpy(&o, outv, 16);
+            *(u32x4*)dst = o;
           }
         }
       }
@@ -524,6 +549,8 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
   int rc = make_plan(d, &p);
   if (rc != SFVOS_OK) return rc;
   SFVOS_REQUIRE(x && w_packed && y && zeros, "conv: null pointer");
+  SFVOS_REQUIRE(!(stat_part && d->accumulate), "conv: statistics are those of the conv result; not available with accumulate");
+  SFVOS_REQUIRE(d->ld_y % (d->dtype == SFVOS_BF16 ? 8 : 4) == 0, "conv: ld_y %d must be a multiple of a 16-byte chunk", d->ld_y);
   SFVOS_REQUIRE(!(d->taps == 1 && p.family == 2), "conv: 1x1 conv with c_out > 64 has no kernel instance");
   ConvArgs a;
   a.x = (const char*)x; a.wp = (const char*)w_packed; a.bias = bias; a.y = (char*)y; a.stat_part = stat_part;
