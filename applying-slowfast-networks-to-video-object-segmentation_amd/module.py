@@ -144,6 +144,8 @@ class SlowFastLayers(nn.Module):
         self._packs = {}     # (conv name, kind, dtype) -> ((param version, data_ptr, epoch), packed tensor)
         self._zeros = None
         self._timer = None
+        self._side = None
+        self.n_streams = int(os.environ.get('SFVOS_STREAMS', '2'))
 
     def enable_kernel_timer(self):
         self._timer = KernelTimer()
@@ -205,6 +207,23 @@ class SlowFastLayers(nn.Module):
             return 'xf0', self.plan.fp, slow_offset
         return layer.src, None, 0
 
+    # ------------------------------------------------------------------ streams
+    def _streams(self, dev):
+        """(main, side): the fast pathway runs on the caller's current stream, the slow pathway (slow convs +
+        laterals) on a side HIP stream; events order the lateral fusions.  The two pathways are independent
+        between fusions, so HBM-bound BN passes of one overlap MFMA-bound convs of the other and launch tails
+        are filled.  SFVOS_STREAMS=1 (or n_streams = 1) serialises everything on the current stream."""
+        main = torch.cuda.current_stream(dev)
+        if self.n_streams < 2:
+            return main, None
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        return main, self._side
+
+    @staticmethod
+    def _on_side(layer):
+        return layer.name[0] in 'sl'
+
     # ------------------------------------------------------------------ forward engine (whole pyramid)
     def _engine_forward(self, shapes, B, xf0, xs0, slow_offset, keep):
         """xf0 / xs0: flat pyramid buffers [B*T*sum(HW), C] in the compute dtype (xs0 None when the slow
@@ -214,7 +233,6 @@ class SlowFastLayers(nn.Module):
         dt_name = self.precision
         dt_id, tdt = _DT[dt_name]
         dev = xf0.device
-        st = _stream()
         zeros = self._zero_page(dev)
         L = len(shapes)
         pix = sum(h * w for h, w in shapes)
@@ -222,76 +240,100 @@ class SlowFastLayers(nn.Module):
         bufs = {'xf0': xf0}
         if xs0 is not None:
             bufs['xs0'] = xs0
-
-        def alloc(name):
-            b = plan.buffers[name]
-            bufs[name] = torch.empty((B * b.frames * pix, b.channels), dtype=tdt, device=dev)
-            return bufs[name]
-
         train = self.training
-        coef = {}
         lib = _lib.load()
+        main, side = self._streams(dev)
+
+        # -- phase 1 (current stream): every buffer and workspace of the pass is allocated, and every weight
+        # image packed, BEFORE the side stream is forked, and nothing is freed until the streams are joined,
+        # so the caching allocator never hands memory still in use on one stream to the other.
+        work = {}
         for l in plan.layers:
-            conv, bn = getattr(self, l.conv), getattr(self, l.bn)
+            for name in (l.raw, l.dst):
+                if name not in bufs:
+                    b = plan.buffers[name]
+                    bufs[name] = torch.empty((B * b.frames * pix, b.channels), dtype=tdt, device=dev)
             sname, t_alloc, t_off = self._src_window(l, slow_offset)
             src = bufs[sname]
-            raw = alloc(l.raw)
-            if l.dst not in bufs:
-                alloc(l.dst)
-            dst = bufs[l.dst]
             d = self._desc(l, B, pyr, dt_id, src.shape[-1], l.c_out, t_alloc, t_off)
             lv = _lib.make_levels(shapes, B, l.t_out)
-            wp = self._packed(l, 'fwd', dt_name)
-            bias = _ptr(conv.bias.detach()) if conv.bias is not None else None
-            cf = torch.empty((L, _CF_ROWS, l.c_out), dtype=torch.float32, device=dev)
-            cs = _CF_ROWS * l.c_out
+            w = dict(d=d, lv=lv, src=src, wp=self._packed(l, 'fwd', dt_name),
+                     cf=torch.empty((L, _CF_ROWS, l.c_out), dtype=torch.float32, device=dev))
             if train:
                 if min(lv.m[i] for i in range(L)) <= 1:
                     raise ValueError('Expected more than 1 value per channel when training, got input size %s'
                                      % str([B, l.c_out, l.t_out] + list(shapes[-1])))
-                rows_pl = (ctypes.c_int * _lib.MAX_LEVELS)()
-                rows = lib.sfvos_conv3d_stat_rows(ctypes.byref(d), rows_pl)
+                w['rows_pl'] = (ctypes.c_int * _lib.MAX_LEVELS)()
+                rows = lib.sfvos_conv3d_stat_rows(ctypes.byref(d), w['rows_pl'])
                 if rows <= 0:
                     _lib.check(rows if rows < 0 else -1, 'sfvos_conv3d_stat_rows')
-                part = torch.empty((rows, 2, l.c_out), dtype=torch.float32, device=dev)
-                with self._t('conv_fwd', l.name):
-                    _lib.call('sfvos_conv3d', ctypes.byref(d), _ptr(src), _ptr(wp), bias, _ptr(raw), _ptr(part),
-                              _ptr(zeros), st)
-                _lib.call('sfvos_bn_finalize', _ptr(part), L, rows_pl, lv.m, _ptr(bn.weight.detach()),
-                          _ptr(bn.bias.detach()), float(bn.eps), l.c_out, _ptr(cf[0, _MEAN]), _ptr(cf[0, _RSTD]),
-                          _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), _ptr(cf[0, _VARU]), cs, st)
-                if bn.track_running_stats and bn.running_mean is not None:
-                    # the reference runs the levels one after another: L consecutive momentum updates
-                    bn.num_batches_tracked.add_(L)
-                    if bn.momentum is None:
-                        raise RuntimeError('BatchNorm momentum=None (cumulative average) is not supported')
-                    _lib.call('sfvos_bn_running_update', _ptr(bn.running_mean), _ptr(bn.running_var),
-                              _ptr(cf[0, _MEAN]), _ptr(cf[0, _VARU]), L, cs, l.c_out, float(bn.momentum), st)
-            else:
-                with self._t('conv_fwd', l.name):
-                    _lib.call('sfvos_conv3d', ctypes.byref(d), _ptr(src), _ptr(wp), bias, _ptr(raw), None, _ptr(zeros),
-                              st)
-                _lib.call('sfvos_bn_eval_coeffs', _ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
-                          _ptr(bn.running_mean), _ptr(bn.running_var), float(bn.eps), l.c_out, _ptr(cf[0, _MEAN]),
-                          _ptr(cf[0, _RSTD]), _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), st)
-                if L > 1:
-                    cf[1:, :4] = cf[0, :4]  # same running statistics for every level (plumbing copy)
-            with self._t('bn_apply', l.name):
-                _lib.call('sfvos_bn_apply', _ptr(raw), l.c_out, _ptr(dst, l.dst_off), dst.shape[-1], dt_id,
-                          ctypes.byref(lv), l.c_out, _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), cs,
-                          1 if l.relu else 0, st)
+                w['rows'] = rows
+                w['part'] = torch.empty((rows, 2, l.c_out), dtype=torch.float32, device=dev)
+            work[l.name] = w
+        merged = [torch.empty((B, 256, H, W), dtype=torch.float32, device=dev) for (H, W) in shapes]
+
+        # -- phase 2: launches
+        if side is not None:
+            side.wait_stream(main)
+        ev = {}
+        coef = {}
+        for l in plan.layers:
+            conv, bn = getattr(self, l.conv), getattr(self, l.bn)
+            w = work[l.name]
+            d, lv, src, wp, cf = w['d'], w['lv'], w['src'], w['wp'], w['cf']
+            raw, dst = bufs[l.raw], bufs[l.dst]
+            cs = _CF_ROWS * l.c_out
+            bias = _ptr(conv.bias.detach()) if conv.bias is not None else None
+            stream = side if (side is not None and self._on_side(l)) else main
+            with torch.cuda.stream(stream):
+                st = _stream()
+                if side is not None:  # lateral fusions: the slow side consumes the fast pathway's activations
+                    if l.name == 'l1' and 'f1' in ev:
+                        stream.wait_event(ev['f1'])
+                    if l.name == 'l2' and 'f2' in ev:
+                        stream.wait_event(ev['f2'])
+                if train:
+                    with self._t('conv_fwd', l.name):
+                        _lib.call('sfvos_conv3d', ctypes.byref(d), _ptr(src), _ptr(wp), bias, _ptr(raw),
+                                  _ptr(w['part']), _ptr(zeros), st)
+                    _lib.call('sfvos_bn_finalize', _ptr(w['part']), L, w['rows_pl'], lv.m, _ptr(bn.weight.detach()),
+                              _ptr(bn.bias.detach()), float(bn.eps), l.c_out, _ptr(cf[0, _MEAN]), _ptr(cf[0, _RSTD]),
+                              _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), _ptr(cf[0, _VARU]), cs, st)
+                    if bn.track_running_stats and bn.running_mean is not None:
+                        # the reference runs the levels one after another: L consecutive momentum updates
+                        bn.num_batches_tracked.add_(L)
+                        if bn.momentum is None:
+                            raise RuntimeError('BatchNorm momentum=None (cumulative average) is not supported')
+                        _lib.call('sfvos_bn_running_update', _ptr(bn.running_mean), _ptr(bn.running_var),
+                                  _ptr(cf[0, _MEAN]), _ptr(cf[0, _VARU]), L, cs, l.c_out, float(bn.momentum), st)
+                else:
+                    with self._t('conv_fwd', l.name):
+                        _lib.call('sfvos_conv3d', ctypes.byref(d), _ptr(src), _ptr(wp), bias, _ptr(raw), None,
+                                  _ptr(zeros), st)
+                    _lib.call('sfvos_bn_eval_coeffs', _ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
+                              _ptr(bn.running_mean), _ptr(bn.running_var), float(bn.eps), l.c_out, _ptr(cf[0, _MEAN]),
+                              _ptr(cf[0, _RSTD]), _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), st)
+                    if L > 1:
+                        cf[1:, :4] = cf[0, :4]  # same running statistics for every level (plumbing copy)
+                with self._t('bn_apply', l.name):
+                    _lib.call('sfvos_bn_apply', _ptr(raw), l.c_out, _ptr(dst, l.dst_off), dst.shape[-1], dt_id,
+                              ctypes.byref(lv), l.c_out, _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), cs,
+                              1 if l.relu else 0, st)
+                if side is not None and l.name in ('f1', 'f2'):
+                    ev[l.name] = torch.cuda.Event()
+                    ev[l.name].record(stream)
             coef[l.name] = cf
+        if side is not None:
+            main.wait_stream(side)
 
         # -- cat([slow224, fast32], 1).squeeze(2) (model.py:162) as the caller's NCHW fp32 tensors
-        merged = []
+        st = _stream()
         off = 0
         out = bufs['out']
-        for (H, W) in shapes:
-            m = torch.empty((B, 256, H, W), dtype=torch.float32, device=dev)
+        for (H, W), m in zip(shapes, merged):
             _lib.call('sfvos_ndhwc_to_frames', _ptr(out, off * 256), dt_id, _ptr(m), 256 * H * W, H * W, W, 1, B, 256,
                       H, W, 256, 0, st)
             off += B * H * W
-            merged.append(m)
         if not keep:
             return merged, None
         state = _State()
@@ -307,11 +349,11 @@ class SlowFastLayers(nn.Module):
         dt_id, tdt = _DT[dt_name]
         B, shapes, bufs, coef = state.B, state.shapes, state.bufs, state.coef
         dev = bufs['xf0'].device
-        st = _stream()
         zeros = self._zero_page(dev)
         lib = _lib.load()
         pix = sum(h * w for h, w in shapes)
         pyr = _lib.make_pyramid(shapes)
+        main, side = self._streams(dev)
         gb = {}  # gradient buffers w.r.t. activation buffers
 
         def galloc(name, zero=False):
@@ -326,13 +368,16 @@ class SlowFastLayers(nn.Module):
             if g is not None:
                 g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
                 _lib.call('sfvos_frames_to_ndhwc', _ptr(g), 256 * H * W, H * W, W, 1, _ptr(gb['out'], off * 256),
-                          dt_id, B, 256, H, W, 256, st)
+                          dt_id, B, 256, H, W, 256, _stream())
             off += B * H * W
-        grads = {}
-        written = set()
+
+        # -- phase 1 (current stream): decide what runs, allocate every buffer / workspace, pack dgrad images
         any_param = any(need_param.values())
+        todo = []
+        written = set()
+        keepalive = []
         for l in reversed(plan.layers):
-            conv, bn = getattr(self, l.conv), getattr(self, l.bn)
+            conv = getattr(self, l.conv)
             first = l.src in ('xs0', 'xf0')
             need_in = (need_slow if l.src == 'xs0' else need_fast) if first else True
             need_w = need_param[l.conv + '.weight']
@@ -343,59 +388,89 @@ class SlowFastLayers(nn.Module):
             if not first and not (any_param or need_slow or need_fast):
                 continue
             lv = _lib.make_levels(shapes, B, l.t_out)
+            rows = lib.sfvos_bn_bwd_rows(ctypes.byref(lv))
+            w = dict(l=l, lv=lv, rows=rows, need_in=need_in, need_w=need_w, need_b=need_b,
+                     part=torch.empty((rows, 2, l.c_out), dtype=torch.float32, device=dev),
+                     dgamma=torch.empty(l.c_out, dtype=torch.float32, device=dev),
+                     dbeta=torch.empty(l.c_out, dtype=torch.float32, device=dev),
+                     dx=torch.empty((_lv_total(lv), l.c_out), dtype=tdt, device=dev))
+            if need_b:
+                w['bpart'] = torch.empty((rows, l.c_out), dtype=torch.float32, device=dev)
+                w['db'] = torch.empty(l.c_out, dtype=torch.float32, device=dev)
+            sname, t_alloc, t_off = self._src_window(l, state.slow_offset)
+            w['src'] = bufs[sname]
+            if need_w:
+                d = self._desc(l, B, pyr, dt_id, w['src'].shape[-1], l.c_out, t_alloc, t_off)
+                nbytes = lib.sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
+                if nbytes == 0:
+                    _lib.check(-1, 'sfvos_conv3d_wgrad_workspace_bytes')
+                w['wd'] = d
+                w['ws'] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                w['gw'] = torch.empty(conv.weight.shape, dtype=torch.float32, device=dev)
+            if need_in:
+                if l.src not in gb:
+                    galloc(l.src)
+                w['acc'] = 1 if l.src in written else 0
+                written.add(l.src)
+                w['dd'] = self._desc(l, B, pyr, dt_id, l.c_out, gb[l.src].shape[-1], dgrad=True, accumulate=w['acc'])
+                w['wpd'] = self._packed(l, 'dgrad', dt_name)
+            todo.append(w)
+            keepalive.append(w)
+
+        # -- phase 2: launches.  Cross-pathway hand-offs: the fast side's data-gradient writes g(y_f2)/g(y_f1)
+        # before the lateral's accumulates into it, and the next fast layer waits for that accumulate.
+        if side is not None:
+            side.wait_stream(main)
+        ev = {}
+        wait_for = {'l2': 'f3', 'f2': 'l2', 'l1': 'f2', 'f1': 'l1'}
+        grads = {}
+        for w in todo:
+            l = w['l']
+            conv, bn = getattr(self, l.conv), getattr(self, l.bn)
+            lv, rows = w['lv'], w['rows']
             cf = coef[l.name]
             cs = _CF_ROWS * l.c_out
             dy = gb[l.dst]
             raw = bufs[l.raw]
-            rows = lib.sfvos_bn_bwd_rows(ctypes.byref(lv))
-            part = torch.empty((rows, 2, l.c_out), dtype=torch.float32, device=dev)
-            treg = self._t('bn_bwd', l.name)
-            treg.__enter__()
-            _lib.call('sfvos_bn_bwd_reduce', _ptr(dy, l.dst_off), dy.shape[-1], _ptr(raw), l.c_out, dt_id,
-                      ctypes.byref(lv), l.c_out, _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), _ptr(cf[0, _MEAN]),
-                      _ptr(cf[0, _RSTD]), cs, 1 if l.relu else 0, _ptr(part), st)
-            dgamma = torch.empty(l.c_out, dtype=torch.float32, device=dev)
-            dbeta = torch.empty(l.c_out, dtype=torch.float32, device=dev)
-            _lib.call('sfvos_bn_bwd_finalize', _ptr(part), ctypes.byref(lv), _ptr(bn.weight.detach()),
-                      _ptr(cf[0, _MEAN]), _ptr(cf[0, _RSTD]), cs, l.c_out, 1 if state.train else 0, 0, _ptr(dgamma),
-                      _ptr(dbeta), _ptr(cf[0, _CA]), _ptr(cf[0, _CB]), _ptr(cf[0, _CK]), st)
-            grads[l.bn + '.weight'], grads[l.bn + '.bias'] = dgamma, dbeta
-            dx = torch.empty((_lv_total(lv), l.c_out), dtype=tdt, device=dev)
-            bpart = torch.empty((rows, l.c_out), dtype=torch.float32, device=dev) if need_b else None
-            _lib.call('sfvos_bn_bwd_apply', _ptr(dy, l.dst_off), dy.shape[-1], _ptr(raw), l.c_out, _ptr(dx), l.c_out,
-                      dt_id, ctypes.byref(lv), l.c_out, _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), cs,
-                      1 if l.relu else 0, _ptr(cf[0, _CA]), _ptr(cf[0, _CB]), _ptr(cf[0, _CK]),
-                      _ptr(bpart) if need_b else None, st)
-            treg.__exit__(None, None, None)
-            if need_b:
-                db = torch.empty(l.c_out, dtype=torch.float32, device=dev)
-                _lib.call('sfvos_reduce_rows', _ptr(bpart), rows, l.c_out, _ptr(db), 0, st)
-                grads[l.conv + '.bias'] = db
-            sname, t_alloc, t_off = self._src_window(l, state.slow_offset)
-            src = bufs[sname]
-            if need_w:
-                d = self._desc(l, B, pyr, dt_id, src.shape[-1], l.c_out, t_alloc, t_off)
-                nbytes = lib.sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
-                if nbytes == 0:
-                    _lib.check(-1, 'sfvos_conv3d_wgrad_workspace_bytes')
-                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                gw = torch.empty(conv.weight.shape, dtype=torch.float32, device=dev)
-                with self._t('wgrad', l.name):
-                    _lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), _ptr(src), _ptr(dx), _ptr(gw), 0, _ptr(ws),
-                              _ptr(zeros), st)
-                grads[l.conv + '.weight'] = gw
-            if need_in:
-                if l.src not in gb:
-                    galloc(l.src)
-                gsrc = gb[l.src]
-                acc = 1 if l.src in written else 0
-                d = self._desc(l, B, pyr, dt_id, l.c_out, gsrc.shape[-1], dgrad=True, accumulate=acc)
-                wp = self._packed(l, 'dgrad', dt_name)
-                with self._t('conv_dgrad', l.name):
-                    _lib.call('sfvos_conv3d', ctypes.byref(d), _ptr(dx), _ptr(wp), None, _ptr(gsrc), None, _ptr(zeros),
-                              st)
-                written.add(l.src)
-            del dx
+            dx = w['dx']
+            stream = side if (side is not None and self._on_side(l)) else main
+            with torch.cuda.stream(stream):
+                st = _stream()
+                dep = wait_for.get(l.name)
+                if side is not None and dep in ev:
+                    stream.wait_event(ev[dep])
+                treg = self._t('bn_bwd', l.name)
+                treg.__enter__()
+                _lib.call('sfvos_bn_bwd_reduce', _ptr(dy, l.dst_off), dy.shape[-1], _ptr(raw), l.c_out, dt_id,
+                          ctypes.byref(lv), l.c_out, _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), _ptr(cf[0, _MEAN]),
+                          _ptr(cf[0, _RSTD]), cs, 1 if l.relu else 0, _ptr(w['part']), st)
+                _lib.call('sfvos_bn_bwd_finalize', _ptr(w['part']), ctypes.byref(lv), _ptr(bn.weight.detach()),
+                          _ptr(cf[0, _MEAN]), _ptr(cf[0, _RSTD]), cs, l.c_out, 1 if state.train else 0, 0,
+                          _ptr(w['dgamma']), _ptr(w['dbeta']), _ptr(cf[0, _CA]), _ptr(cf[0, _CB]), _ptr(cf[0, _CK]), st)
+                grads[l.bn + '.weight'], grads[l.bn + '.bias'] = w['dgamma'], w['dbeta']
+                _lib.call('sfvos_bn_bwd_apply', _ptr(dy, l.dst_off), dy.shape[-1], _ptr(raw), l.c_out, _ptr(dx),
+                          l.c_out, dt_id, ctypes.byref(lv), l.c_out, _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), cs,
+                          1 if l.relu else 0, _ptr(cf[0, _CA]), _ptr(cf[0, _CB]), _ptr(cf[0, _CK]),
+                          _ptr(w['bpart']) if w['need_b'] else None, st)
+                treg.__exit__(None, None, None)
+                if w['need_b']:
+                    _lib.call('sfvos_reduce_rows', _ptr(w['bpart']), rows, l.c_out, _ptr(w['db']), 0, st)
+                    grads[l.conv + '.bias'] = w['db']
+                if w['need_in']:  # data gradient first: the other pathway may be waiting for it
+                    with self._t('conv_dgrad', l.name):
+                        _lib.call('sfvos_conv3d', ctypes.byref(w['dd']), _ptr(dx), _ptr(w['wpd']), None,
+                                  _ptr(gb[l.src]), None, _ptr(zeros), st)
+                    if side is not None:
+                        ev[l.name] = torch.cuda.Event()
+                        ev[l.name].record(stream)
+                if w['need_w']:
+                    with self._t('wgrad', l.name):
+                        _lib.call('sfvos_conv3d_wgrad', ctypes.byref(w['wd']), _ptr(w['src']), _ptr(dx), _ptr(w['gw']),
+                                  0, _ptr(w['ws']), _ptr(zeros), st)
+                    grads[l.conv + '.weight'] = w['gw']
+        if side is not None:
+            main.wait_stream(side)
+        del keepalive  # workspaces are released only after the join
         return grads, gb
 
     # ------------------------------------------------------------------ input layout

@@ -31,6 +31,10 @@ def parse():
     ap.add_argument('--sp', type=int, default=4)
     ap.add_argument('--fp', type=int, default=32)
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--streams', type=int, default=1,
+                    help='HIP streams per clip: 1 = every launch on one stream (clean per-kernel HIP-event / rocprof '
+                         'durations, the default here); 2 = slow pathway on a side stream (module default, ~5 %% '
+                         'more clips/s, but concurrent kernels stretch each other\'s measured duration)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=0)
     return ap.parse_args()
@@ -93,6 +97,7 @@ def main():
     torch.manual_seed(63)
     model = SlowFastLayers(256, dev, args.sp, args.fp, precision=args.precision).to(dev)
     model.train()
+    model.n_streams = args.streams
     opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
     bucket = GradBucket(opt.flat_grad)
     tdt = torch.bfloat16 if args.precision == 'bf16' else torch.float32
@@ -160,7 +165,7 @@ def main():
             'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
             'config': {'workload': 'SlowFastLayers (sp=%d, fp=%d) fwd+bwd+SGD, 1 clip/GPU/step, 5 FPN levels of a '
                                    '480x854 frame (P=%d), NDHWC inputs resident in HBM' % (args.sp, args.fp, P),
-                       'parallelism': 'dp%d' % world, 'grad_accumulation': 2},
+                       'parallelism': 'dp%d' % world, 'grad_accumulation': 2, 'hip_streams_per_clip': args.streams},
             'tflops_per_clip': round(total_flops / 1e12, 3),
             'achieved_tflops_whole_step': round(total_flops * world * args.steps / dt / 1e12, 2),
             'roofline': roofline,
