@@ -20,11 +20,11 @@ def init_distributed(backend=None):
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend is None:  # SFVOS_DIST_BACKEND=gloo: rehearse the multi-rank control flow without RCCL
+            backend = os.environ.get('SFVOS_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 

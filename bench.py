@@ -91,7 +91,7 @@ def main():
     if world != args.gpus:
         if rank == 0 and world > 1:
             print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
-    dev = torch.device('cuda', local if world > 1 else 0)
+    dev = torch.device('cuda', (local % torch.cuda.device_count()) if world > 1 else 0)
     torch.cuda.set_device(dev)
 
     torch.manual_seed(63)
@@ -153,10 +153,28 @@ def main():
             ach = dom_flops / (dom[1] * 1e-3) / 1e12
             roofline = {'bound': 'mfma',
                         'kernel': 'sfvos::conv3d_kernel<1,9,9,4,1,1,8,1,256> + <1,9,9,3,1,1,8,1,256> '
-                                  '(fast_conv1 forward, 256->32 ch, 11x3x3, frames 0-15 / 16-21, 5-level pyramid)',
+                                  '(fast_conv1 forward, 256->32 ch, %dx3x3, %d->%d frames in blocks of 4 and 3, '
+                                  '5-level pyramid)' % (l.kt, l.t_in, l.t_out),
                         'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                         'launch_ms': round(dom[1], 4), 'flops_per_launch': dom_flops,
                         'traffic': pmc_traffic(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json'))}
+        # HBM-bound passes: algorithmic bytes (each tensor touched once per pass) / HIP-event time
+        es = 2 if args.precision == 'bf16' else 4
+        hbm = {}
+        for kind, passes in (('bn_apply', 2), ('bn_bwd', 5)):   # apply: read x, write y; bwd: 2x(dy, x) + write dx
+            nbytes = sum(l.t_out * P * l.c_out * es * passes for l in plan.layers)
+            ms = sum(kern[k][1] for k in kern if k.startswith(kind + '/'))
+            if ms > 0:
+                hbm[kind] = {'gbytes': round(nbytes / 1e9, 3), 'ms': round(ms, 4),
+                             'achieved_GBps': round(nbytes / ms / 1e6, 1), 'peak_GBps': 8000.0,
+                             'frac': round(nbytes / ms / 1e6 / 8000.0, 4)}
+        mfma = {}
+        fl = plan.layer_flops(P)
+        for kind in ('conv_fwd', 'wgrad', 'conv_dgrad'):
+            for l in plan.layers:
+                k = '%s/%s' % (kind, l.name)
+                if k in kern:
+                    mfma[k] = {'ms': round(kern[k][1], 4), 'TFLOPs': round(fl[l.name] / kern[k][1] / 1e9, 1)}
         total_flops = plan.train_flops(P)
         line = {
             'metric': 'clips/sec (T=32, 480x854) fwd+bwd', 'value': round(world * args.steps / dt, 4),
@@ -169,6 +187,8 @@ def main():
             'tflops_per_clip': round(total_flops / 1e12, 3),
             'achieved_tflops_whole_step': round(total_flops * world * args.steps / dt / 1e12, 2),
             'roofline': roofline,
+            'hbm_bound_passes': hbm,
+            'mfma_layers': mfma,
             'kernels_ms': {k: [v[0], round(v[1], 4)] for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:24]},
         }
         if not args.no_cpu_baseline and world == 1:
