@@ -59,6 +59,9 @@ struct ConvArgs {
   int t_first, t_end;      // output frames [t_first, t_end) of this launch (a layer may take two launches:
   int tb_offset, t_blocks_total;  // blocks of TT and of TT-1 frames so that no frame slot is padding)
   int debug;  // timing-only: bit0 skip compute, bit1 skip DMA after the first stage (results wrong)
+  // frame-split kernel only: ONE launch holds the blocks of 4, 2 and 1 frames (part 0, 1, 2), big blocks first,
+  // so the short workgroups fill the tail of the long ones; lv.wg_begin then counts per frame block.
+  struct Part { int wgs, t_blocks, t_first, t_end, tb_offset; } part[3];
 #ifdef SFVOS_STAMP
   unsigned long long* stamps;  // diagnostic build only: s_memtime stamps of one workgroup
 #endif
@@ -388,12 +391,350 @@ __global__ __launch_bounds__(64 * WS * WN, (WS * WN) / 4) void conv3d_kernel(Con
   }
 }
 
+// ---- frame-split kernel for kt x 3 x 3 convs with c_out <= 32 ----------------------------------------
+// With one 32-channel output tile every pixel fragment feeds ONE MFMA, so in the generic kernel above the
+// LDS, not the matrix pipe, paces such layers (1.25 ds_read_b128 per MFMA per wave).  Here the eight waves of
+// a workgroup split the 8 rows x 32 px x TT frames x 32 channels tile by FRAME, ROW GROUP and K HALF:
+//   wave (j, rs, kh): output frame j, rows rs*MT .. rs*MT+MT-1, 16-byte chunks {2kh, 2kh+1} of every 64-byte
+//   channel group.  For each column shift dw it walks the MT+2 halo rows once: the fragment of halo row rr
+//   serves the MFMAs of the three (output row i, dh) pairs with i + dh = rr, and the three weight fragments
+//   (dh, dw) stay in registers for the whole walk -> (3 (MT+2) + 9) reads per 9 MT MFMAs (0.54 per MFMA at
+//   MT = 8).  The two K halves of a tile are summed through LDS once, after the K loop; each partner then
+//   finishes MT/2 of the rows (bias, store, statistics).
+// Ring, LDS images, staging, XCD order and the statistics rows are those of conv3d_kernel.
+template <int DT, int TT, int RS>
+struct FsCfg {
+  static constexpr int NWAVES = 8, NTHREADS = 512;
+  static constexpr int MT = 8 / RS, HM = MT / 2, TH = 8, TW = 32, HR = TH + 2, HC = TW + 2, BN = 32;
+  static constexpr int R = TT + 1;
+  static constexpr int X_SLOTS = 4 * HR * HC;
+  static constexpr int X_BYTES = ((X_SLOTS * 16 + 255) / 256) * 256;
+  static constexpr int W_SLOTS = 9 * 4 * BN;
+  static constexpr int W_BYTES = W_SLOTS * 16;
+  static constexpr int XCH_BYTES = NWAVES * HM * 4096;  // K-half exchange: HM accumulator tiles per wave
+  static constexpr int STAGE_BYTES = R * X_BYTES + 2 * W_BYTES;
+  static constexpr int LDS_BYTES = STAGE_BYTES > XCH_BYTES ? STAGE_BYTES : XCH_BYTES;
+  static_assert(TT * RS == 4 && HM >= 1, "eight waves = TT frames x RS row groups x 2 K halves");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <int DT, int TT, int RS, int CIN>
+__device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const ConvArgs::Part& pt) {
+  typedef FsCfg<DT, TT, RS> C;
+  typedef typename Elt<DT>::type T;
+  constexpr int CE = Elt<DT>::CE, CK = 4 * CE, ES = 16 / CE, MT = C::MT, HM = C::HM;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ring = smem;
+  char* const wbase = smem + C::R * C::X_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kh = wv >> 2, jf = (wv & 3) / RS, rs = (wv & 3) % RS;  // K-half partners (wv, wv^4) share a SIMD
+  const int r = lane & 31, hh = lane >> 5;
+
+  int lvl = 0;
+#pragma unroll
+  for (int l = 1; l < SFVOS_MAX_LEVELS; ++l)
+    if (l < a.lv.n && wg >= a.lv.wg_begin[l] * pt.t_blocks) lvl = l;
+  const int H = a.lv.H[lvl], W = a.lv.W[lvl], tiles_w = a.lv.tiles_w[lvl], tiles_h = a.lv.tiles_h[lvl];
+  int bid = wg - a.lv.wg_begin[lvl] * pt.t_blocks;  // XCD-aware order, as in conv3d_kernel
+  const int per_group = 8 * pt.t_blocks;
+  const int grp = bid / per_group, rem = bid - grp * per_group;
+  const int tb = rem >> 3;
+  const int ntile = tiles_h * tiles_w, tgroups = (ntile + 7) >> 3;
+  const int tile = (grp % tgroups) * 8 + (rem & 7);
+  if (tile >= ntile) return;
+  const int b = grp / tgroups;
+  const int th = tile / tiles_w, tw = tile - th * tiles_w;
+  const int h0 = th * C::TH, w0 = tw * C::TW, tb0 = pt.t_first + tb * TT;
+
+  const int NF = TT + a.kt - 1;
+  const int ncc = (CIN ? CIN : a.c_in) / CK;
+  const long long HWp = (long long)H * W;
+  const char* xclip = a.x + (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset) * HWp) * a.ld_x * ES;
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  constexpr int NX = (C::X_SLOTS + C::NTHREADS - 1) / C::NTHREADS;
+  constexpr int NW = (C::W_SLOTS + C::NTHREADS - 1) / C::NTHREADS;
+  int xo[NX], wo[NW];  // >= 0 offset ; -1 zero page (padding) ; -2 no slot
+#pragma unroll
+  for (int it = 0; it < NX; ++it) {
+    // pixel-major image: slot = (row*HC + col)*4 + (chunk ^ ((col>>2)&3)).  Four consecutive lanes copy the four
+    // 16-byte chunks of ONE pixel (a 64-byte run of global memory), so the copy is coalesced; the XOR spreads
+    // the 16 lanes of a ds_read_b128 group (same chunk, 16 different columns) over all 64 banks.
+    const int sl = it * C::NTHREADS + tid;
+    const int cq = sl & 3, rc = sl >> 2, col = rc % C::HC, row = rc / C::HC;
+    const int j = cq ^ ((col >> 2) & 3);
+    const int h = h0 + row - 1, w = w0 + col - 1;
+    const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+#ifdef SFVOS_GROUPED_TEST
+    xo[it] = sl >= C::X_SLOTS ? -2 : (ok ? (int)((((long long)h * W + w) * CK + j * CE) * ES) : -1);
+#else
+    xo[it] = sl >= C::X_SLOTS ? -2 : (ok ? (int)((((long long)h * W + w) * a.ld_x + j * CE) * ES) : -1);
+#endif
+  }
+  int xsw[3];  // lane part of an A-fragment address for column shift dw (chunk 2kh+hh of pixel column r+dw)
+#pragma unroll
+  for (int dw = 0; dw < 3; ++dw) xsw[dw] = ((r + dw) * 4 + ((2 * kh + hh) ^ (((r + dw) >> 2) & 3))) * 16;
+#pragma unroll
+  for (int it = 0; it < NW; ++it) {
+    const int sl = it * C::NTHREADS + tid;
+    const int tj = sl / C::BN, n = sl - tj * C::BN;  // tj = tap*4 + chunk
+    wo[it] = (sl < C::W_SLOTS && n < a.c_out) ? (tj * a.c_out + n) * 16 : -2;
+  }
+  const int lds_wave_off = wv * 1024;
+
+  struct Dma {
+    const char* xsrc; char* xb; bool do_x, t_ok;
+    const char* wsrc; char* wb; bool do_w;
+  };
+  constexpr int NPIECE = NX + NW;
+  auto wrap = [](int sl) { return sl >= C::R ? sl - C::R : sl; };
+  auto prep_frame = [&](Dma& d, int cc, int i, int slot) {
+    const int t = tb0 - a.pad_t + i;
+    d.do_x = true;
+    d.t_ok = (unsigned)t < (unsigned)a.t_in;
+    d.xb = ring + slot * C::X_BYTES + lds_wave_off;
+#ifdef SFVOS_GROUPED_TEST  // timing experiment: x as [channel group][position][64 B]
+    d.xsrc = a.x + (long long)cc * (85932ll * a.t_alloc * 64) +
+             (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset + t) * HWp) * 64;
+#else
+    d.xsrc = xclip + ((long long)t * HWp * a.ld_x + cc * CK) * ES;
+#endif
+  };
+  auto prep_w = [&](Dma& d, int cc, int dt, int s) {  // weight slice of stage s: [9 taps][4 chunks][32]
+    d.do_w = true;
+    d.wb = wbase + (s & 1) * C::W_BYTES + lds_wave_off;
+    d.wsrc = a.wp + ((long long)(cc * a.kt + dt) * 9 * 4 * a.c_out) * 16;
+  };
+  auto piece = [&](const Dma& d, int p) {
+    if (p < NX) {
+      if (d.do_x && xo[p] > -2) {
+        const char* src = (d.t_ok && xo[p] >= 0) ? d.xsrc + xo[p] : a.zeros;
+        glds16(src, d.xb + p * (C::NTHREADS * 16));
+      }
+    } else {
+      const int q = p - NX;
+      if (d.do_w && wo[q] > -2) glds16(d.wsrc + wo[q], d.wb + q * (C::NTHREADS * 16));
+    }
+  };
+  auto issue_all = [&](const Dma& d) {
+#pragma unroll
+    for (int p = 0; p < NPIECE; ++p) piece(d, p);
+  };
+
+  // ---- one stage = (channel group cc, temporal tap dt): 9 MT MFMAs per wave --------------------------
+  auto compute = [&](int s, int fslot, const Dma& d) {
+    const char* wbl = wbase + (s & 1) * C::W_BYTES + ((2 * kh + hh) * C::BN + r) * 16;
+    const char* xfl = ring + wrap(fslot + jf) * C::X_BYTES + rs * MT * C::HC * 64;
+    constexpr int ROWS = MT + 2, NA = 3 * ROWS, PDA = 3, PSTEP = NA / NPIECE;
+    static_assert(PSTEP >= 1, "DMA pieces must fit the step count");
+    u32x4 av[PDA], bw[2][3];
+    auto load_a = [&](int t) {
+      const int dw = t / ROWS, rr = t - dw * ROWS;
+      av[t % PDA] = lds_read16(xfl + xsw[dw] + rr * C::HC * 64);
+    };
+    auto load_b = [&](int dw) {
+#pragma unroll
+      for (int dh = 0; dh < 3; ++dh) bw[dw & 1][dh] = lds_read16(wbl + ((dh * 3 + dw) * 4 * C::BN) * 16);
+    };
+    load_b(0);
+    load_a(0);
+    load_a(1);
+#pragma unroll
+    for (int t = 0; t < NA; ++t) {
+      const int dw = t / ROWS, rr = t - dw * ROWS;
+      if (t + PDA - 1 < NA && !(a.debug & 64)) {
+        if ((t + PDA - 1) % ROWS == 0) load_b((t + PDA - 1) / ROWS);
+        load_a(t + PDA - 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // reads of step t+2 stay ahead of the MFMAs of step t
+#pragma unroll
+      for (int dh = 0; dh < 3; ++dh) {
+        const int i = rr - dh;
+        if (i >= 0 && i < MT) Mma<DT>::run(acc[i], av[t % PDA], bw[dw & 1][dh]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (t % PSTEP == PSTEP / 2 && t / PSTEP < NPIECE) piece(d, t / PSTEP);
+    }
+  };
+
+  // ---- main loop (same ring schedule as conv3d_kernel with one tap group per temporal tap) ----------
+  const int dt_lo = max(0, a.pad_t - tb0 - (TT - 1));
+  const int dt_hi = min(a.kt - 1, a.pad_t - tb0 + a.t_in - 1);
+  const int S = ncc * max(0, dt_hi - dt_lo + 1);
+  int s = 0;
+#ifdef SFVOS_STAMP
+  if (a.stamps && blockIdx.x == 300 && lane == 0) {
+    a.stamps[8 * 128 * 4 + wv * 4 + 0] = __builtin_amdgcn_s_memtime();
+    a.stamps[8 * 128 * 4 + wv * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+  for (int cc = 0; cc < ncc && S > 0; ++cc) {
+    if (cc > 0) __syncthreads();
+    int fslot = (cc * NF + dt_lo) % C::R;
+    for (int i = 0; i < TT; ++i) {
+      Dma d; d.do_w = false;
+      prep_frame(d, cc, dt_lo + i, wrap(fslot + i));
+      issue_all(d);
+    }
+    if (cc == 0) {
+      Dma d; d.do_x = false;
+      prep_w(d, 0, dt_lo, 0);
+      issue_all(d);
+    }
+    for (int dt = dt_lo; dt <= dt_hi; ++dt, ++s) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      SFVOS_STAMP_AT(3)
+      if (!(a.debug & 16)) __syncthreads();
+      SFVOS_STAMP_AT(0)
+      Dma d; d.do_x = d.do_w = false;
+      if (dt < dt_hi && !(a.debug & 2)) prep_frame(d, cc, dt + TT, wrap(fslot + TT));
+      if (s + 1 < S && !(a.debug & 2)) {
+        int ndt = dt + 1, ncc2 = cc;
+        if (ndt > dt_hi) { ndt = dt_lo; ++ncc2; }
+        prep_w(d, ncc2, ndt, s + 1);
+      }
+      SFVOS_STAMP_AT(1)
+      if (!(a.debug & 1)) compute(s, fslot, d);
+      else issue_all(d);
+      SFVOS_STAMP_AT(2)
+      fslot = wrap(fslot + 1);
+    }
+  }
+
+#ifdef SFVOS_STAMP
+  if (a.stamps && blockIdx.x == 300 && lane == 0) {
+    a.stamps[8 * 128 * 4 + wv * 4 + 2] = __builtin_amdgcn_s_memtime();
+    a.stamps[8 * 128 * 4 + wv * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+  // ---- K-half exchange: each partner hands the other the tiles it will not finish ----------------------
+  __syncthreads();  // ring / weight buffers are dead
+  f32x16 fin[HM];
+  {
+    f32x4* mine = (f32x4*)(smem + wv * (HM * 4096)) + lane;
+    const f32x4* theirs = (const f32x4*)(smem + (wv ^ 4) * (HM * 4096)) + lane;
+    if (kh == 0) {
+#pragma unroll
+      for (int ii = 0; ii < HM; ++ii)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          mine[(ii * 4 + g) * 64] = f32x4{acc[HM + ii][4 * g], acc[HM + ii][4 * g + 1], acc[HM + ii][4 * g + 2],
+                                          acc[HM + ii][4 * g + 3]};
+    } else {
+#pragma unroll
+      for (int ii = 0; ii < HM; ++ii)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          mine[(ii * 4 + g) * 64] = f32x4{acc[ii][4 * g], acc[ii][4 * g + 1], acc[ii][4 * g + 2], acc[ii][4 * g + 3]};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ii = 0; ii < HM; ++ii) {
+      if (kh == 0) fin[ii] = acc[ii];
+      else fin[ii] = acc[HM + ii];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 o = theirs[(ii * 4 + g) * 64];
+        // fixed order: K half 0 + K half 1
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fin[ii][4 * g + u] = kh == 0 ? fin[ii][4 * g + u] + o[u] : o[u] + fin[ii][4 * g + u];
+      }
+    }
+    __syncthreads();  // exchange area is dead: the per-wave transposition scratch below overlays it
+  }
+
+  // ---- epilogue: rows kh*HM .. kh*HM+HM-1 of the wave's frame (as conv3d_kernel's, one channel tile) ----
+  float s1 = 0.f, s2 = 0.f;
+  T* yclip = (T*)a.y + (a.lv.ypos[lvl] + (long long)b * a.t_out * HWp) * a.ld_y;
+  float* scr = (float*)smem + wv * (32 * 33);
+  constexpr int CPP = 32 / CE;
+  const int to = tb0 + jf;
+  if (r < a.c_out && to < pt.t_end) {  // c_out is a multiple of 32: always true for r; kept for symmetry
+    const float bias = a.bias ? a.bias[r] : 0.f;
+#pragma unroll
+    for (int ii = 0; ii < HM; ++ii) {
+      const int h = h0 + rs * MT + kh * HM + ii;
+      if (h >= H) continue;  // wave-uniform
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int px = (e & 3) + 8 * (e >> 2) + 4 * hh;
+        const float v = fin[ii][e] + bias;
+        scr[px * 33 + r] = v;
+        if (w0 + px < W) { s1 += v; s2 += v * v; }
+      }
+      T* yrow = yclip + ((long long)(to * H + h) * W + w0) * a.ld_y;
+#pragma unroll
+      for (int it = 0; it < (32 * CPP) / 64; ++it) {
+        const int idx = it * 64 + lane, px = idx / CPP, ch = (idx % CPP) * CE;
+        float f[CE];
+#pragma unroll
+        for (int u = 0; u < CE; ++u) f[u] = scr[px * 33 + ch + u];
+        if (w0 + px < W) {
+          T* dst = yrow + (long long)px * a.ld_y + ch;
+          if (a.accumulate) {
+            const u32x4 old = *(const u32x4*)dst;
+            T oldv[CE];
+            __builtin_memcpy(oldv, &old, 16);
+#pragma unroll
+            for (int u = 0; u < CE; ++u) f[u] += Elt<DT>::to_f32(oldv[u]);
+          }
+          T outv[CE];
+#pragma unroll
+          for (int u = 0; u < CE; ++u) outv[u] = Elt<DT>::from_f32(f[u]);
+          u32x4 o;
+          __builtin_memcpy(&o, outv, 16);
+          *(u32x4*)dst = o;
+        }
+      }
+    }
+  }
+  if (a.stat_part) {
+    __syncthreads();
+    float* red = (float*)smem;  // [8 waves][32][2]
+    const float t1 = s1 + __shfl_xor(s1, 32), t2 = s2 + __shfl_xor(s2, 32);
+    if (lane < 32) {
+      red[(wv * 32 + lane) * 2 + 0] = t1;
+      red[(wv * 32 + lane) * 2 + 1] = t2;
+    }
+    __syncthreads();
+    if (tid < 32 && tid < a.c_out) {
+      float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < C::NWAVES; ++k) {
+        u1 += red[(k * 32 + tid) * 2 + 0];
+        u2 += red[(k * 32 + tid) * 2 + 1];
+      }
+      const long long prow = a.lv.row_begin[lvl] +
+                             ((long long)(b * a.t_blocks_total + pt.tb_offset + tb) * tiles_h + th) * tiles_w + tw;
+      a.stat_part[(prow * 2 + 0) * a.c_out + tid] = u1;
+      a.stat_part[(prow * 2 + 1) * a.c_out + tid] = u2;
+    }
+  }
+}
+
+template <int DT, int CIN = 0>
+__global__ __launch_bounds__(512, 2) void conv3d_fs_kernel(ConvArgs a) {
+  int wg = blockIdx.x;  // workgroup-uniform three-way split: blocks of 4 frames, then of 2, then of 1
+  if (wg < a.part[0].wgs) return fs_body<DT, 4, 1, CIN>(a, wg, a.part[0]);
+  wg -= a.part[0].wgs;
+  if (wg < a.part[1].wgs) return fs_body<DT, 2, 2, CIN>(a, wg, a.part[1]);
+  wg -= a.part[1].wgs;
+  fs_body<DT, 1, 4, CIN>(a, wg, a.part[2]);
+}
+
 // ---- host-side planning ----------------------------------------------------------------------------
 struct ConvPlan {
-  int family;  // 0 narrow (c_out <= 32), 1 mid (c_out == 64, 1x1), 2 wide
+  int family;  // 0 narrow 1x1 (c_out <= 32), 1 mid (c_out == 64, 1x1), 2 wide, 3 frame-split (c_out <= 32, 3x3)
   int TT, NT, TH, BN;
   int t_blocks, n_blocks, t_out;  // t_blocks = total frame blocks
-  int n_launch, l_tt[2], l_blocks[2], l_first[2];  // launches: blocks of l_tt frames starting at frame l_first
+  int n_launch, l_tt[3], l_blocks[3], l_first[3];  // launches: blocks of l_tt frames starting at frame l_first
   ConvLevels lv;
 };
 
@@ -412,6 +753,73 @@ static void split_frames(int t_out, int max_tt, ConvPlan* p) {
   p->l_tt[p->n_launch] = base; p->l_blocks[p->n_launch] = nblk - rem; p->l_first[p->n_launch] = rem * (base + 1);
   ++p->n_launch;
   p->TT = p->l_tt[0];
+}
+
+// Frame-split kernel: n4 blocks of 4 frames, n2 of 2, n1 of 1 per pixel tile, all in ONE launch, dispatched
+// big blocks first.  Workgroups of a launch go to compute units as these free up, so the launch ends when the
+// last unit drains: with equal blocks the final round can be nearly empty (362 tiles x 5 blocks = 7.07 rounds
+// of 256 -> 8).  The split is chosen by simulating that greedy dispatch with relative block costs; trading a
+// block of 4 for two of 2 costs some efficiency per frame but lets short blocks fill the tail.
+static int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+           prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return cus;
+}
+
+static double greedy_makespan(long long units, const int n[3], const double cost[3], int cus) {
+  double t[64]; long long k[64]; int g = 1;  // groups of units that free up at the same time
+  t[0] = 0.0; k[0] = cus;
+  for (int c = 0; c < 3; ++c) {
+    long long left = units * n[c];
+    while (left > 0) {
+      int e = 0;
+      for (int i = 1; i < g; ++i) if (t[i] < t[e]) e = i;
+      const long long m = left < k[e] ? left : k[e];
+      const double done = t[e] + cost[c];
+      k[e] -= m; left -= m;
+      if (k[e] == 0) { t[e] = t[g - 1]; k[e] = k[g - 1]; --g; }
+      int j = 0;
+      for (; j < g; ++j) if (t[j] == done) break;
+      if (j == g) { if (g == 64) return 1e30; t[g] = done; k[g] = 0; ++g; }
+      k[j] += m;
+    }
+  }
+  double end = 0.0;
+  for (int i = 0; i < g; ++i) if (k[i] > 0 && t[i] > end) end = t[i];
+  return end;
+}
+
+static void split_frames_balanced(int t_out, long long units, ConvPlan* p) {
+  static const double cost[3] = {1.0, 0.7, 0.5};  // measured relative workgroup times of 4 / 2 / 1 frame blocks
+  const int cus = device_cus();
+  int best[3] = {t_out / 4, (t_out % 4) / 2, t_out % 2};
+  double best_t = greedy_makespan(units, best, cost, cus);
+  for (int n4 = t_out / 4 - 1; n4 >= 0 && n4 >= t_out / 4 - 2; --n4) {
+    const int rest = t_out - 4 * n4;
+    const int cand[3] = {n4, rest / 2, rest % 2};
+    const double t = greedy_makespan(units, cand, cost, cus);
+    if (t < best_t * 0.995) { best_t = t; best[0] = cand[0]; best[1] = cand[1]; best[2] = cand[2]; }
+  }
+  if (const char* ov = getenv("SFVOS_FS_SPLIT")) {  // tuning aid: "n4,n2,n1" (must cover t_out exactly)
+    int v[3];
+    if (sscanf(ov, "%d,%d,%d", &v[0], &v[1], &v[2]) == 3 && v[0] >= 0 && v[1] >= 0 && v[2] >= 0 &&
+        4 * v[0] + 2 * v[1] + v[2] == t_out) { best[0] = v[0]; best[1] = v[1]; best[2] = v[2]; }
+  }
+  p->t_blocks = 0;
+  p->n_launch = 3;  // parts of the single launch; empty parts have 0 blocks
+  int first = 0;
+  for (int c = 0; c < 3; ++c) {
+    const int tt = 4 >> c;
+    p->l_tt[c] = tt; p->l_blocks[c] = best[c]; p->l_first[c] = first;
+    first += best[c] * tt;
+    p->t_blocks += best[c];
+  }
+  p->TT = 4;
 }
 
 static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
@@ -433,12 +841,13 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
   p->t_out = d->t_in + 2 * d->pad_t - d->kt + 1;
   SFVOS_REQUIRE(p->t_out >= 1, "conv: kernel longer than padded input (t_in %d, kt %d, pad_t %d)", d->t_in, d->kt,
                 d->pad_t);
-#ifdef SFVOS_CONV_4WAVES
-  constexpr int WNW = 1;  // waves across the channel dimension
-#else
-  constexpr int WNW = 2;
-#endif
-  if (d->c_out <= 32) {
+  constexpr int WNW = 2;  // waves across the channel dimension (mid / wide families)
+  if (d->c_out <= 32 && d->taps == 9) {
+    long long units = 0;
+    for (int l = 0; l < d->pyr.n_levels && l < SFVOS_MAX_LEVELS; ++l)
+      units += (long long)d->batch * ceil_div(d->pyr.h[l] > 0 ? d->pyr.h[l] : 1, 8) * ceil_div(d->pyr.w[l] > 0 ? d->pyr.w[l] : 1, 32);
+    p->family = 3; split_frames_balanced(p->t_out, units, p); p->NT = 1; p->TH = 8; p->BN = 32;
+  } else if (d->c_out <= 32) {
     p->family = 0; split_frames(p->t_out, 4, p); p->NT = 1; p->TH = 8; p->BN = 32;
   } else if (d->c_out == 64 && d->taps == 1) {
     p->family = 1; split_frames(p->t_out, 3, p); p->NT = 2 / WNW; p->TH = 8; p->BN = 64;
@@ -494,30 +903,33 @@ static int launch(const ConvArgs& a, long long grid, hipStream_t stream) {
   return check_launch("conv3d");
 }
 
+template <int DT, int CIN = 0>
+static int launch_fs(const ConvArgs& a, long long grid, hipStream_t stream) {
+  constexpr int LDS = FsCfg<DT, 4, 1>::LDS_BYTES;  // the largest of the three bodies
+  static_assert(LDS >= FsCfg<DT, 2, 2>::LDS_BYTES && LDS >= FsCfg<DT, 1, 4>::LDS_BYTES, "LDS of the merged launch");
+  auto kern = conv3d_fs_kernel<DT, CIN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      set_error("conv: hipFuncSetAttribute(%d B LDS) failed: %s", LDS, hipGetErrorString(e));
+      return SFVOS_E_LAUNCH;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, stream, a);
+  return check_launch("conv3d_fs");
+}
+
 template <int DT, int TAPS>
 static int dispatch(const ConvPlan& p, const ConvArgs& a, long long grid, hipStream_t s) {
 #define SFVOS_CASE(F, TPSv, TTv, MTv, NTv, WSv, WNv) \
   if (p.family == F && p.TT == TTv && p.NT == NTv) return launch<DT, TAPS, TPSv, TTv, MTv, NTv, WSv, WNv>(a, grid, s);
-  constexpr int NTPS = TAPS == 9 ? 9 : 1;
-#ifdef SFVOS_CONV_4WAVES
-  // one wave per SIMD: narrow wave = two rows, all frames; wide wave = one row, all channels
-  SFVOS_CASE(0, NTPS, 1, 2, 1, 4, 1) SFVOS_CASE(0, NTPS, 2, 2, 1, 4, 1) SFVOS_CASE(0, NTPS, 3, 2, 1, 4, 1)
-  SFVOS_CASE(0, NTPS, 4, 2, 1, 4, 1)
+  // two waves per SIMD
   if constexpr (TAPS == 1) {
-    SFVOS_CASE(1, 1, 1, 2, 2, 4, 1) SFVOS_CASE(1, 1, 2, 2, 2, 4, 1) SFVOS_CASE(1, 1, 3, 2, 2, 4, 1)
-  } else {
-    SFVOS_CASE(2, 3, 1, 1, 6, 4, 1) SFVOS_CASE(2, 3, 2, 1, 6, 4, 1)
-    SFVOS_CASE(2, 3, 1, 1, 8, 4, 1) SFVOS_CASE(2, 3, 2, 1, 8, 4, 1)
-  }
-#else
-  // two waves per SIMD.  narrow: 8 rows x 32 px x TT frames x 32 channels; wave = one row, all frames
-  if constexpr (TAPS == 9 && DT == SFVOS_BF16) {  // fast_conv1 forward (256 -> 32): own symbols
-    if (p.family == 0 && a.c_in == 256 && p.TT == 4) return launch<DT, TAPS, 9, 4, 1, 1, 8, 1, 256>(a, grid, s);
-    if (p.family == 0 && a.c_in == 256 && p.TT == 3) return launch<DT, TAPS, 9, 3, 1, 1, 8, 1, 256>(a, grid, s);
-  }
-  SFVOS_CASE(0, NTPS, 1, 1, 1, 8, 1) SFVOS_CASE(0, NTPS, 2, 1, 1, 8, 1) SFVOS_CASE(0, NTPS, 3, 1, 1, 8, 1)
-  SFVOS_CASE(0, NTPS, 4, 1, 1, 8, 1)
-  if constexpr (TAPS == 1) {
+    // narrow 1x1 (lateral data gradient 64 -> 32): 8 rows x 32 px x TT frames x 32 channels; wave = one row
+    SFVOS_CASE(0, 1, 1, 1, 1, 8, 1) SFVOS_CASE(0, 1, 2, 1, 1, 8, 1) SFVOS_CASE(0, 1, 3, 1, 1, 8, 1)
+    SFVOS_CASE(0, 1, 4, 1, 1, 8, 1)
     // mid (lateral 32->64): 8 rows x 32 px x TT frames x 64 channels
     SFVOS_CASE(1, 1, 1, 2, 1, 4, 2) SFVOS_CASE(1, 1, 2, 2, 1, 4, 2) SFVOS_CASE(1, 1, 3, 2, 1, 4, 2)
   } else {
@@ -525,7 +937,6 @@ static int dispatch(const ConvPlan& p, const ConvArgs& a, long long grid, hipStr
     SFVOS_CASE(2, 3, 1, 1, 3, 4, 2) SFVOS_CASE(2, 3, 2, 1, 3, 4, 2) SFVOS_CASE(2, 3, 3, 1, 3, 4, 2)
     SFVOS_CASE(2, 3, 1, 1, 4, 4, 2) SFVOS_CASE(2, 3, 2, 1, 4, 4, 2)
   }
-#endif
 #undef SFVOS_CASE
   set_error("conv: no kernel instance for family %d TT %d NT %d taps %d", p.family, p.TT, p.NT, TAPS);
   return SFVOS_E_ARG;
@@ -565,6 +976,26 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
 #endif
   hipStream_t s = (hipStream_t)stream;
   int tb_offset = 0;
+  if (p.family == 3) {  // one launch: blocks of 4, 2 and 1 frames as parts 0, 1, 2
+    a.lv = p.lv;        // wg_begin counts per frame block; the kernel scales it by the part's block count
+    a.t_blocks = a.t_first = a.t_end = a.tb_offset = 0;
+    long long grid = 0;
+    for (int c = 0; c < 3; ++c) {
+      ConvArgs::Part& pt = a.part[c];
+      pt.t_blocks = p.l_blocks[c]; pt.t_first = p.l_first[c]; pt.t_end = pt.t_first + p.l_tt[c] * pt.t_blocks;
+      pt.tb_offset = tb_offset;
+      tb_offset += pt.t_blocks;
+      const long long wgs = (long long)p.lv.wg_begin[SFVOS_MAX_LEVELS] * pt.t_blocks;
+      SFVOS_REQUIRE(wgs < (1ll << 31), "conv: grid out of range");
+      pt.wgs = (int)wgs;
+      grid += wgs;
+    }
+    SFVOS_REQUIRE(grid > 0 && grid < (1ll << 31), "conv: grid %lld out of range", grid);
+    if (d->dtype == SFVOS_BF16)
+      return d->c_in == 256 ? launch_fs<SFVOS_BF16, 256>(a, grid, s) : launch_fs<SFVOS_BF16>(a, grid, s);
+    return launch_fs<SFVOS_F32>(a, grid, s);
+  }
+  for (int c = 0; c < 3; ++c) a.part[c] = ConvArgs::Part{0, 0, 0, 0, 0};
   for (int li = 0; li < p.n_launch; ++li) {
     p.TT = p.l_tt[li];
     a.t_blocks = p.l_blocks[li]; a.t_first = p.l_first[li]; a.t_end = a.t_first + p.l_tt[li] * p.l_blocks[li];
