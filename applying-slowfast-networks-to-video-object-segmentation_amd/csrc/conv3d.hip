@@ -408,7 +408,7 @@ struct FsCfg {
   static constexpr int MT = 8 / RS, HM = MT / 2, TH = 8, TW = 32, HR = TH + 2, HC = TW + 2, BN = 32;
   static constexpr int R = TT + 1;
   static constexpr int X_SLOTS = 4 * HR * HC;
-  static constexpr int X_BYTES = ((X_SLOTS * 16 + 255) / 256) * 256;
+  static constexpr int X_BYTES = ((X_SLOTS + 63) / 64) * 1024;  // whole 64-slot wave-pieces (the tail is padding)
   static constexpr int W_SLOTS = 9 * 4 * BN;
   static constexpr int W_BYTES = W_SLOTS * 16;
   static constexpr int XCH_BYTES = NWAVES * HM * 4096;  // K-half exchange: HM accumulator tiles per wave
@@ -418,19 +418,24 @@ struct FsCfg {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <int DT, int TT, int RS, int CIN>
+// M16 (bf16 only): the MFMAs are v_mfma_f32_16x16x32_bf16 -- one instruction consumes a pixel's whole 64-byte
+// channel group, so the two wave halves split the 32 pixel columns instead of K (no exchange at the end).  Same
+// cycles per FLOP as 32x32x16, but the chip holds a higher clock on this shape under load.
+template <int DT, int TT, int RS, int CIN, bool M16>
 __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const ConvArgs::Part& pt) {
   typedef FsCfg<DT, TT, RS> C;
   typedef typename Elt<DT>::type T;
   constexpr int CE = Elt<DT>::CE, CK = 4 * CE, ES = 16 / CE, MT = C::MT, HM = C::HM;
+  static_assert(!M16 || DT == SFVOS_BF16, "16x16x32 is the bf16 path");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ring = smem;
   char* const wbase = smem + C::R * C::X_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kh = wv >> 2, jf = (wv & 3) / RS, rs = (wv & 3) % RS;  // K-half partners (wv, wv^4) share a SIMD
-  const int r = lane & 31, hh = lane >> 5;
+  const int kh = wv >> 2, jf = (wv & 3) / RS, rs = (wv & 3) % RS;  // half partners (wv, wv^4) share a SIMD
+  const int r = lane & 31, hh = lane >> 5;   // 32x32x16 fragments: row r, K half hh
+  const int p16 = lane & 15, g16 = lane >> 4;  // 16x16x32 fragments: row p16, 16-byte chunk g16
 
   int lvl = 0;
 #pragma unroll
@@ -453,44 +458,57 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
   const long long HWp = (long long)H * W;
   const char* xclip = a.x + (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset) * HWp) * a.ld_x * ES;
 
-  f32x16 acc[MT];
+  f32x16 acc[M16 ? 1 : MT];   // 32x32 tiles: [row]
+  f32x4 acc16[M16 ? MT : 1][2];  // 16x16 tiles: [row][channel half]
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int i = 0; i < (M16 ? 1 : MT); ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < (M16 ? MT : 1); ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc16[i][0][e] = acc16[i][1][e] = 0.f;
 
-  constexpr int NX = (C::X_SLOTS + C::NTHREADS - 1) / C::NTHREADS;
-  constexpr int NW = (C::W_SLOTS + C::NTHREADS - 1) / C::NTHREADS;
-  int xo[NX], wo[NW];  // >= 0 offset ; -1 zero page (padding) ; -2 no slot
+  // ---- staging: buffer_load ... lds (LDS-DMA through a buffer descriptor).  A copy is (descriptor of the frame /
+  // weight slice, per-lane byte offset fixed for the whole kernel): padding pixels and frames outside the clip
+  // carry an out-of-range offset / an empty descriptor and the hardware range check writes zeros for them, so a
+  // piece costs two scalar instructions and no vector ALU work.  Pieces are whole wave-instructions (64 slots);
+  // wave w owns pieces w, w+8, w+16 of an image.
+  constexpr int XWP = (C::X_SLOTS + 63) / 64, WWP = (C::W_SLOTS + 63) / 64;  // wave-pieces per frame / weight slice
+  constexpr int NX = (XWP + 7) / 8, NW = (WWP + 7) / 8;
+  static_assert(C::X_BYTES >= XWP * 1024 && C::W_BYTES >= WWP * 1024, "staging images hold whole wave-pieces");
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned xo[NX], wo[NW];
 #pragma unroll
   for (int it = 0; it < NX; ++it) {
-    // pixel-major image: slot = (row*HC + col)*4 + (chunk ^ ((col>>2)&3)).  Four consecutive lanes copy the four
+    // pixel-major image: slot = (row*HC + col)*4 + (chunk ^ swz(col)).  Four consecutive lanes copy the four
     // 16-byte chunks of ONE pixel (a 64-byte run of global memory), so the copy is coalesced; the XOR spreads
-    // the 16 lanes of a ds_read_b128 group (same chunk, 16 different columns) over all 64 banks.
+    // the 16 lanes of a ds_read_b128 group over all 64 banks: swz = (col>>2)&3 for the 32x32x16 fragments (same
+    // chunk, 16 columns), 2*((col>>2)&1) for the 16x16x32 ones (two chunks x 8 columns per group).
     const int sl = it * C::NTHREADS + tid;
     const int cq = sl & 3, rc = sl >> 2, col = rc % C::HC, row = rc / C::HC;
-    const int j = cq ^ ((col >> 2) & 3);
+    const int j = cq ^ (M16 ? 2 * ((col >> 2) & 1) : ((col >> 2) & 3));
     const int h = h0 + row - 1, w = w0 + col - 1;
-    const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
-#ifdef SFVOS_GROUPED_TEST
-    xo[it] = sl >= C::X_SLOTS ? -2 : (ok ? (int)((((long long)h * W + w) * CK + j * CE) * ES) : -1);
-#else
-    xo[it] = sl >= C::X_SLOTS ? -2 : (ok ? (int)((((long long)h * W + w) * a.ld_x + j * CE) * ES) : -1);
-#endif
+    const bool ok = sl < C::X_SLOTS && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+    xo[it] = ok ? (unsigned)((((long long)h * W + w) * a.ld_x + j * CE) * ES) : OOB;
   }
   int xsw[3];  // lane part of an A-fragment address for column shift dw (chunk 2kh+hh of pixel column r+dw)
 #pragma unroll
-  for (int dw = 0; dw < 3; ++dw) xsw[dw] = ((r + dw) * 4 + ((2 * kh + hh) ^ (((r + dw) >> 2) & 3))) * 16;
+  for (int dw = 0; dw < 3; ++dw) {
+    const int col = M16 ? kh * 16 + p16 + dw : r + dw;
+    xsw[dw] = M16 ? (col * 4 + (g16 ^ (2 * ((col >> 2) & 1)))) * 16 : (col * 4 + ((2 * kh + hh) ^ ((col >> 2) & 3))) * 16;
+  }
 #pragma unroll
   for (int it = 0; it < NW; ++it) {
     const int sl = it * C::NTHREADS + tid;
     const int tj = sl / C::BN, n = sl - tj * C::BN;  // tj = tap*4 + chunk
-    wo[it] = (sl < C::W_SLOTS && n < a.c_out) ? (tj * a.c_out + n) * 16 : -2;
+    wo[it] = (sl < C::W_SLOTS && n < a.c_out) ? (unsigned)((tj * a.c_out + n) * 16) : OOB;
   }
   const int lds_wave_off = wv * 1024;
+  const int frame_bytes = (int)(HWp * a.ld_x * ES), wslice_bytes = 9 * 4 * a.c_out * 16;
 
   struct Dma {
-    const char* xsrc; char* xb; bool do_x, t_ok;
+    const char* xsrc; char* xb; int xrec; bool do_x;
     const char* wsrc; char* wb; bool do_w;
   };
   constexpr int NPIECE = NX + NW;
@@ -498,14 +516,9 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
   auto prep_frame = [&](Dma& d, int cc, int i, int slot) {
     const int t = tb0 - a.pad_t + i;
     d.do_x = true;
-    d.t_ok = (unsigned)t < (unsigned)a.t_in;
+    d.xrec = (unsigned)t < (unsigned)a.t_in ? frame_bytes - cc * CK * ES : 0;  // frame outside the clip: all zeros
     d.xb = ring + slot * C::X_BYTES + lds_wave_off;
-#ifdef SFVOS_GROUPED_TEST  // timing experiment: x as [channel group][position][64 B]
-    d.xsrc = a.x + (long long)cc * (85932ll * a.t_alloc * 64) +
-             (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset + t) * HWp) * 64;
-#else
-    d.xsrc = xclip + ((long long)t * HWp * a.ld_x + cc * CK) * ES;
-#endif
+    d.xsrc = xclip + ((long long)((unsigned)t < (unsigned)a.t_in ? t : 0) * HWp * a.ld_x + cc * CK) * ES;
   };
   auto prep_w = [&](Dma& d, int cc, int dt, int s) {  // weight slice of stage s: [9 taps][4 chunks][32]
     d.do_w = true;
@@ -514,13 +527,16 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
   };
   auto piece = [&](const Dma& d, int p) {
     if (p < NX) {
-      if (d.do_x && xo[p] > -2) {
-        const char* src = (d.t_ok && xo[p] >= 0) ? d.xsrc + xo[p] : a.zeros;
-        glds16(src, d.xb + p * (C::NTHREADS * 16));
+      if (d.do_x && p * 8 + wv < XWP) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)d.xsrc, 0, d.xrec, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (SFVOS_LDS void*)(d.xb + p * (C::NTHREADS * 16)), 16, xo[p], 0, 0, 0);
       }
     } else {
       const int q = p - NX;
-      if (d.do_w && wo[q] > -2) glds16(d.wsrc + wo[q], d.wb + q * (C::NTHREADS * 16));
+      if (d.do_w && q * 8 + wv < WWP) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)d.wsrc, 0, wslice_bytes, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (SFVOS_LDS void*)(d.wb + q * (C::NTHREADS * 16)), 16, wo[q], 0, 0, 0);
+      }
     }
   };
   auto issue_all = [&](const Dma& d) {
@@ -528,20 +544,47 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
     for (int p = 0; p < NPIECE; ++p) piece(d, p);
   };
 
-  // ---- one stage = (channel group cc, temporal tap dt): 9 MT MFMAs per wave --------------------------
-  auto compute = [&](int s, int fslot, const Dma& d) {
-    const char* wbl = wbase + (s & 1) * C::W_BYTES + ((2 * kh + hh) * C::BN + r) * 16;
-    const char* xfl = ring + wrap(fslot + jf) * C::X_BYTES + rs * MT * C::HC * 64;
-    constexpr int ROWS = MT + 2, NA = 3 * ROWS, PDA = 3, PSTEP = NA / NPIECE;
-    static_assert(PSTEP >= 1, "DMA pieces must fit the step count");
-    u32x4 av[PDA], bw[2][3];
+  // ---- stage bookkeeping: stage = (channel group cc, temporal tap dt); fslot = ring slot of frame dt --------
+  const int dt_lo = max(0, a.pad_t - tb0 - (TT - 1));  // temporal taps that can touch a real frame (see conv3d_kernel)
+  const int dt_hi = min(a.kt - 1, a.pad_t - tb0 + a.t_in - 1);
+  const int S = ncc * max(0, dt_hi - dt_lo + 1);
+  struct Stage { int cc, dt, fslot; };
+  auto next_of = [&](const Stage& x) {
+    Stage n = x;
+    if (x.dt < dt_hi) { n.dt = x.dt + 1; n.fslot = wrap(x.fslot + 1); }
+    else { n.cc = x.cc + 1; n.dt = dt_lo; n.fslot = (n.cc * NF + dt_lo) % C::R; }
+    return n;
+  };
+  // the copy that runs DURING stage x (index s): the next ring frame of this chunk and the next stage's weights
+  auto prep_stage = [&](Dma& d, const Stage& x, int s) {
+    d.do_x = d.do_w = false;
+    if (a.debug & 2) return;
+    if (x.dt < dt_hi) prep_frame(d, x.cc, x.dt + TT, wrap(x.fslot + TT));
+    if (s + 1 < S) {
+      const Stage n = next_of(x);
+      prep_w(d, n.cc, n.dt, s + 1);
+    }
+  };
+
+  // ---- one stage: 9 MT MFMAs per wave.  Its copy (descriptor d, prepared during the PREVIOUS stage) is issued
+  // in the first steps, so it has most of the stage to land; the scalar work for the next stage's descriptor
+  // runs after the first MFMA group, in the shadow of the matrix pipe, not between barrier and first MFMA.
+  auto compute = [&](int s, const Stage& cur, const Dma& d, Dma& dn, const Stage& nx) {
+    const char* wbl = wbase + (s & 1) * C::W_BYTES + (M16 ? g16 * C::BN + p16 : (2 * kh + hh) * C::BN + r) * 16;
+    const char* xfl = ring + wrap(cur.fslot + jf) * C::X_BYTES + rs * MT * C::HC * 64;
+    constexpr int ROWS = MT + 2, NA = 3 * ROWS, PDA = 3, NH = M16 ? 2 : 1;
+    static_assert(2 * NPIECE <= NA, "DMA pieces must fit the step count");
+    u32x4 av[PDA], bw[2][3][NH];
     auto load_a = [&](int t) {
       const int dw = t / ROWS, rr = t - dw * ROWS;
       av[t % PDA] = lds_read16(xfl + xsw[dw] + rr * C::HC * 64);
     };
     auto load_b = [&](int dw) {
 #pragma unroll
-      for (int dh = 0; dh < 3; ++dh) bw[dw & 1][dh] = lds_read16(wbl + ((dh * 3 + dw) * 4 * C::BN) * 16);
+      for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+        for (int nh = 0; nh < NH; ++nh)
+          bw[dw & 1][dh][nh] = lds_read16(wbl + ((dh * 3 + dw) * 4 * C::BN + nh * 16) * 16);
     };
     load_b(0);
     load_a(0);
@@ -557,17 +600,29 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
 #pragma unroll
       for (int dh = 0; dh < 3; ++dh) {
         const int i = rr - dh;
-        if (i >= 0 && i < MT) Mma<DT>::run(acc[i], av[t % PDA], bw[dw & 1][dh]);
+        if (i >= 0 && i < MT) {
+          if constexpr (M16) {
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+              acc16[i][nh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[t % PDA]),
+                                                                    __builtin_bit_cast(bf16x8, bw[dw & 1][dh][nh]),
+                                                                    acc16[i][nh], 0, 0, 0);
+          } else {
+            Mma<DT>::run(acc[i], av[t % PDA], bw[dw & 1][dh][0]);
+          }
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (t % PSTEP == PSTEP / 2 && t / PSTEP < NPIECE) piece(d, t / PSTEP);
+      if (t % 2 == 0 && t / 2 < NPIECE) piece(d, t / 2);
+      if (t == 1) {
+        if (s + 1 < S) prep_stage(dn, nx, s + 1);
+        else dn.do_x = dn.do_w = false;
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
 
-  // ---- main loop (same ring schedule as conv3d_kernel with one tap group per temporal tap) ----------
-  const int dt_lo = max(0, a.pad_t - tb0 - (TT - 1));
-  const int dt_hi = min(a.kt - 1, a.pad_t - tb0 + a.t_in - 1);
-  const int S = ncc * max(0, dt_hi - dt_lo + 1);
+  // ---- main loop ----------------------------------------------------------------------------------------
   int s = 0;
 #ifdef SFVOS_STAMP
   if (a.stamps && blockIdx.x == 300 && lane == 0) {
@@ -575,37 +630,37 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
     a.stamps[8 * 128 * 4 + wv * 4 + 1] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
-  for (int cc = 0; cc < ncc && S > 0; ++cc) {
-    if (cc > 0) __syncthreads();
-    int fslot = (cc * NF + dt_lo) % C::R;
-    for (int i = 0; i < TT; ++i) {
-      Dma d; d.do_w = false;
-      prep_frame(d, cc, dt_lo + i, wrap(fslot + i));
-      issue_all(d);
-    }
-    if (cc == 0) {
-      Dma d; d.do_x = false;
-      prep_w(d, 0, dt_lo, 0);
-      issue_all(d);
-    }
-    for (int dt = dt_lo; dt <= dt_hi; ++dt, ++s) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      SFVOS_STAMP_AT(3)
-      if (!(a.debug & 16)) __syncthreads();
-      SFVOS_STAMP_AT(0)
-      Dma d; d.do_x = d.do_w = false;
-      if (dt < dt_hi && !(a.debug & 2)) prep_frame(d, cc, dt + TT, wrap(fslot + TT));
-      if (s + 1 < S && !(a.debug & 2)) {
-        int ndt = dt + 1, ncc2 = cc;
-        if (ndt > dt_hi) { ndt = dt_lo; ++ncc2; }
-        prep_w(d, ncc2, ndt, s + 1);
+  Stage cur{0, dt_lo, dt_lo % C::R};
+  Dma d; d.do_x = d.do_w = false;
+  if (S > 0) {
+    prep_stage(d, cur, 0);
+    Dma w0; w0.do_x = false;
+    prep_w(w0, 0, dt_lo, 0);
+    issue_all(w0);
+  }
+  for (; s < S; ++s) {
+    if (cur.dt == dt_lo) {
+      // chunk prologue: refill the ring with the first TT frames of this chunk.  All waves must have
+      // finished the previous chunk's last stage before its live slots are overwritten.
+      if (cur.cc > 0) __syncthreads();
+      for (int i = 0; i < TT; ++i) {
+        Dma f; f.do_w = false;
+        prep_frame(f, cur.cc, dt_lo + i, wrap(cur.fslot + i));
+        issue_all(f);
       }
-      SFVOS_STAMP_AT(1)
-      if (!(a.debug & 1)) compute(s, fslot, d);
-      else issue_all(d);
-      SFVOS_STAMP_AT(2)
-      fslot = wrap(fslot + 1);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SFVOS_STAMP_AT(3)
+    if (!(a.debug & 16)) __syncthreads();
+    SFVOS_STAMP_AT(0)
+    const Stage nx = next_of(cur);
+    Dma dn;
+    SFVOS_STAMP_AT(1)
+    if (!(a.debug & 1)) compute(s, cur, d, dn, nx);
+    else { issue_all(d); if (s + 1 < S) prep_stage(dn, nx, s + 1); else dn.do_x = dn.do_w = false; }
+    SFVOS_STAMP_AT(2)
+    d = dn;
+    cur = nx;
   }
 
 #ifdef SFVOS_STAMP
@@ -614,94 +669,149 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
     a.stamps[8 * 128 * 4 + wv * 4 + 3] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
-  // ---- K-half exchange: each partner hands the other the tiles it will not finish ----------------------
-  __syncthreads();  // ring / weight buffers are dead
-  f32x16 fin[HM];
-  {
-    f32x4* mine = (f32x4*)(smem + wv * (HM * 4096)) + lane;
-    const f32x4* theirs = (const f32x4*)(smem + (wv ^ 4) * (HM * 4096)) + lane;
-    if (kh == 0) {
-#pragma unroll
-      for (int ii = 0; ii < HM; ++ii)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          mine[(ii * 4 + g) * 64] = f32x4{acc[HM + ii][4 * g], acc[HM + ii][4 * g + 1], acc[HM + ii][4 * g + 2],
-                                          acc[HM + ii][4 * g + 3]};
-    } else {
-#pragma unroll
-      for (int ii = 0; ii < HM; ++ii)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          mine[(ii * 4 + g) * 64] = f32x4{acc[ii][4 * g], acc[ii][4 * g + 1], acc[ii][4 * g + 2], acc[ii][4 * g + 3]};
-    }
-    __syncthreads();
-#pragma unroll
-    for (int ii = 0; ii < HM; ++ii) {
-      if (kh == 0) fin[ii] = acc[ii];
-      else fin[ii] = acc[HM + ii];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 o = theirs[(ii * 4 + g) * 64];
-        // fixed order: K half 0 + K half 1
-#pragma unroll
-        for (int u = 0; u < 4; ++u) fin[ii][4 * g + u] = kh == 0 ? fin[ii][4 * g + u] + o[u] : o[u] + fin[ii][4 * g + u];
-      }
-    }
-    __syncthreads();  // exchange area is dead: the per-wave transposition scratch below overlays it
-  }
-
-  // ---- epilogue: rows kh*HM .. kh*HM+HM-1 of the wave's frame (as conv3d_kernel's, one channel tile) ----
-  float s1 = 0.f, s2 = 0.f;
+  float s1 = 0.f, s2 = 0.f;  // per-lane partial statistics of channel r (32x32) / channels p16, 16+p16 (16x16)
+  float s1b = 0.f, s2b = 0.f;
   T* yclip = (T*)a.y + (a.lv.ypos[lvl] + (long long)b * a.t_out * HWp) * a.ld_y;
-  float* scr = (float*)smem + wv * (32 * 33);
-  constexpr int CPP = 32 / CE;
   const int to = tb0 + jf;
-  if (r < a.c_out && to < pt.t_end) {  // c_out is a multiple of 32: always true for r; kept for symmetry
-    const float bias = a.bias ? a.bias[r] : 0.f;
+  __syncthreads();  // ring / weight buffers are dead
+  if constexpr (M16) {
+    // ---- epilogue, 16x16 tiles: the wave's 16 pixel columns x 32 channels of each row go through a per-wave
+    // f32 scratch and leave as one 16-byte chunk per lane (lane -> pixel lane/4, channels 8*(lane%4)..+7)
+    float* scr = (float*)smem + wv * (16 * 33);
+    const float bias0 = a.bias ? a.bias[p16] : 0.f, bias1 = a.bias ? a.bias[16 + p16] : 0.f;
+    if (to < pt.t_end) {
 #pragma unroll
-    for (int ii = 0; ii < HM; ++ii) {
-      const int h = h0 + rs * MT + kh * HM + ii;
-      if (h >= H) continue;  // wave-uniform
+      for (int i = 0; i < MT; ++i) {
+        const int h = h0 + rs * MT + i;
+        if (h >= H) continue;  // wave-uniform
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int px = (e & 3) + 8 * (e >> 2) + 4 * hh;
-        const float v = fin[ii][e] + bias;
-        scr[px * 33 + r] = v;
-        if (w0 + px < W) { s1 += v; s2 += v * v; }
-      }
-      T* yrow = yclip + ((long long)(to * H + h) * W + w0) * a.ld_y;
+        for (int e = 0; e < 4; ++e) {
+          const int px = 4 * g16 + e;
+          const float v0 = acc16[i][0][e] + bias0, v1 = acc16[i][1][e] + bias1;
+          scr[px * 33 + p16] = v0;
+          scr[px * 33 + 16 + p16] = v1;
+          if (w0 + kh * 16 + px < W) { s1 += v0; s2 += v0 * v0; s1b += v1; s2b += v1 * v1; }
+        }
+        const int px = lane >> 2, ch = (lane & 3) * 8;
+        float f[8];
 #pragma unroll
-      for (int it = 0; it < (32 * CPP) / 64; ++it) {
-        const int idx = it * 64 + lane, px = idx / CPP, ch = (idx % CPP) * CE;
-        float f[CE];
-#pragma unroll
-        for (int u = 0; u < CE; ++u) f[u] = scr[px * 33 + ch + u];
-        if (w0 + px < W) {
-          T* dst = yrow + (long long)px * a.ld_y + ch;
+        for (int u = 0; u < 8; ++u) f[u] = scr[px * 33 + ch + u];
+        if (w0 + kh * 16 + px < W) {
+          T* dst = yclip + ((long long)(to * H + h) * W + w0 + kh * 16 + px) * a.ld_y + ch;
           if (a.accumulate) {
             const u32x4 old = *(const u32x4*)dst;
-            T oldv[CE];
+            T oldv[8];
             __builtin_memcpy(oldv, &old, 16);
 #pragma unroll
-            for (int u = 0; u < CE; ++u) f[u] += Elt<DT>::to_f32(oldv[u]);
+            for (int u = 0; u < 8; ++u) f[u] += Elt<DT>::to_f32(oldv[u]);
           }
-          T outv[CE];
+          T outv[8];
 #pragma unroll
-          for (int u = 0; u < CE; ++u) outv[u] = Elt<DT>::from_f32(f[u]);
+          for (int u = 0; u < 8; ++u) outv[u] = Elt<DT>::from_f32(f[u]);
           u32x4 o;
           __builtin_memcpy(&o, outv, 16);
           *(u32x4*)dst = o;
         }
       }
     }
-  }
+  } else {
+// ---- K-half exchange: each partner hands the other the tiles it will not finish ----------------------
+    f32x16 fin[HM];
+    {
+      f32x4* mine = (f32x4*)(smem + wv * (HM * 4096)) + lane;
+      const f32x4* theirs = (const f32x4*)(smem + (wv ^ 4) * (HM * 4096)) + lane;
+      if (kh == 0) {
+  #pragma unroll
+        for (int ii = 0; ii < HM; ++ii)
+  #pragma unroll
+          for (int g = 0; g < 4; ++g)
+            mine[(ii * 4 + g) * 64] = f32x4{acc[HM + ii][4 * g], acc[HM + ii][4 * g + 1], acc[HM + ii][4 * g + 2],
+                                            acc[HM + ii][4 * g + 3]};
+      } else {
+  #pragma unroll
+        for (int ii = 0; ii < HM; ++ii)
+  #pragma unroll
+          for (int g = 0; g < 4; ++g)
+            mine[(ii * 4 + g) * 64] = f32x4{acc[ii][4 * g], acc[ii][4 * g + 1], acc[ii][4 * g + 2], acc[ii][4 * g + 3]};
+      }
+      __syncthreads();
+  #pragma unroll
+      for (int ii = 0; ii < HM; ++ii) {
+        if (kh == 0) fin[ii] = acc[ii];
+        else fin[ii] = acc[HM + ii];
+  #pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 o = theirs[(ii * 4 + g) * 64];
+          // fixed order: K half 0 + K half 1
+  #pragma unroll
+          for (int u = 0; u < 4; ++u) fin[ii][4 * g + u] = kh == 0 ? fin[ii][4 * g + u] + o[u] : o[u] + fin[ii][4 * g + u];
+        }
+      }
+      __syncthreads();  // exchange area is dead: the per-wave transposition scratch below overlays it
+    }
+  
+    // ---- epilogue: rows kh*HM .. kh*HM+HM-1 of the wave's frame (as conv3d_kernel's, one channel tile) ----
+    float* scr = (float*)smem + wv * (32 * 33);
+    constexpr int CPP = 32 / CE;
+    if (r < a.c_out && to < pt.t_end) {  // c_out is a multiple of 32: always true for r; kept for symmetry
+      const float bias = a.bias ? a.bias[r] : 0.f;
+  #pragma unroll
+      for (int ii = 0; ii < HM; ++ii) {
+        const int h = h0 + rs * MT + kh * HM + ii;
+        if (h >= H) continue;  // wave-uniform
+  #pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int px = (e & 3) + 8 * (e >> 2) + 4 * hh;
+          const float v = fin[ii][e] + bias;
+          scr[px * 33 + r] = v;
+          if (w0 + px < W) { s1 += v; s2 += v * v; }
+        }
+        T* yrow = yclip + ((long long)(to * H + h) * W + w0) * a.ld_y;
+  #pragma unroll
+        for (int it = 0; it < (32 * CPP) / 64; ++it) {
+          const int idx = it * 64 + lane, px = idx / CPP, ch = (idx % CPP) * CE;
+          float f[CE];
+  #pragma unroll
+          for (int u = 0; u < CE; ++u) f[u] = scr[px * 33 + ch + u];
+          if (w0 + px < W) {
+            T* dst = yrow + (long long)px * a.ld_y + ch;
+            if (a.accumulate) {
+              const u32x4 old = *(const u32x4*)dst;
+              T oldv[CE];
+              __builtin_memcpy(oldv, &old, 16);
+  #pragma unroll
+              for (int u = 0; u < CE; ++u) f[u] += Elt<DT>::to_f32(oldv[u]);
+            }
+            T outv[CE];
+  #pragma unroll
+            for (int u = 0; u < CE; ++u) outv[u] = Elt<DT>::from_f32(f[u]);
+            u32x4 o;
+            __builtin_memcpy(&o, outv, 16);
+            *(u32x4*)dst = o;
+          }
+        }
+      }
+    }
+}
   if (a.stat_part) {
     __syncthreads();
     float* red = (float*)smem;  // [8 waves][32][2]
-    const float t1 = s1 + __shfl_xor(s1, 32), t2 = s2 + __shfl_xor(s2, 32);
-    if (lane < 32) {
-      red[(wv * 32 + lane) * 2 + 0] = t1;
-      red[(wv * 32 + lane) * 2 + 1] = t2;
+    if constexpr (M16) {
+      float t1 = s1 + __shfl_xor(s1, 16), t2 = s2 + __shfl_xor(s2, 16);
+      float t1b = s1b + __shfl_xor(s1b, 16), t2b = s2b + __shfl_xor(s2b, 16);
+      t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32); t1b += __shfl_xor(t1b, 32); t2b += __shfl_xor(t2b, 32);
+      if (lane < 16) {
+        red[(wv * 32 + lane) * 2 + 0] = t1;
+        red[(wv * 32 + lane) * 2 + 1] = t2;
+        red[(wv * 32 + 16 + lane) * 2 + 0] = t1b;
+        red[(wv * 32 + 16 + lane) * 2 + 1] = t2b;
+      }
+    } else {
+      const float t1 = s1 + __shfl_xor(s1, 32), t2 = s2 + __shfl_xor(s2, 32);
+      if (lane < 32) {
+        red[(wv * 32 + lane) * 2 + 0] = t1;
+        red[(wv * 32 + lane) * 2 + 1] = t2;
+      }
     }
     __syncthreads();
     if (tid < 32 && tid < a.c_out) {
@@ -722,11 +832,21 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
 template <int DT, int CIN = 0>
 __global__ __launch_bounds__(512, 2) void conv3d_fs_kernel(ConvArgs a) {
   int wg = blockIdx.x;  // workgroup-uniform three-way split: blocks of 4 frames, then of 2, then of 1
-  if (wg < a.part[0].wgs) return fs_body<DT, 4, 1, CIN>(a, wg, a.part[0]);
-  wg -= a.part[0].wgs;
-  if (wg < a.part[1].wgs) return fs_body<DT, 2, 2, CIN>(a, wg, a.part[1]);
-  wg -= a.part[1].wgs;
-  fs_body<DT, 1, 4, CIN>(a, wg, a.part[2]);
+#ifdef SFVOS_STAMP  // diagnostic build: per-workgroup timeline (start, end, HW_ID, XCC_ID)
+  unsigned long long* tl = a.stamps ? a.stamps + 8 * 128 * 4 + 64 + 4ull * blockIdx.x : nullptr;
+  if (tl && threadIdx.x == 0) {
+    tl[0] = __builtin_amdgcn_s_memrealtime();
+    tl[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    tl[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+  }
+#endif
+  constexpr bool M16 = DT == SFVOS_BF16;
+  if (wg < a.part[0].wgs) fs_body<DT, 4, 1, CIN, M16>(a, wg, a.part[0]);
+  else if (wg - a.part[0].wgs < a.part[1].wgs) fs_body<DT, 2, 2, CIN, M16>(a, wg - a.part[0].wgs, a.part[1]);
+  else fs_body<DT, 1, 4, CIN, M16>(a, wg - a.part[0].wgs - a.part[1].wgs, a.part[2]);
+#ifdef SFVOS_STAMP
+  if (tl && threadIdx.x == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---- host-side planning ----------------------------------------------------------------------------
