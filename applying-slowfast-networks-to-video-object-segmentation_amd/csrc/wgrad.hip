@@ -11,13 +11,17 @@
 //
 // One workgroup (8 waves) owns NTN n-tiles x NTC c-tiles x DG temporal taps x all spatial taps;
 // wave = one (n-tile, c-tile, dt) group with TAPS accumulator tiles.  It sweeps its share of the
-// TH x 16 pixel tiles; for each tile it walks the input frames t: stage (tile, t) holds the halo
-// tile of x[t] (double-buffered) and a ring of the DG+1 newest dy frames, so x[t] is paired with
-// dy[t-dt] for all DG taps of the group from ONE load (x traffic / DG), and exactly one x tile +
-// one dy frame are DMA'd per stage (global_load_lds, one barrier per stage).
+// TH x 16 pixel tiles; stage (tile, fo) pairs the dy frame fo with the x frames fo+dt, dt = dt0..dt0+DG-1:
+// the halo tiles of the x frames live in a ring of R slots that is filled in the order the frames are
+// needed -- across tile boundaries too -- and dy frames are double-buffered, so EVERY wave multiplies at
+// EVERY stage (x traffic / DG, one new x tile + one dy frame per stage, one barrier per stage).
+// Staging is buffer_load ... lds: pixels outside the image, channels past the tensor and the padding
+// lanes of a piece carry an out-of-range offset and are zero-filled by the hardware range check.
 // Split-K partials go to fp32 slabs, summed in a fixed order by wgrad_reduce_kernel
 // (deterministic, no atomics), which also transposes into the state-dict layout
 // [Cout][Cin][kt][kh][kw].
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace sfvos {
@@ -41,7 +45,7 @@ struct WgradArgs {
   WgradLevels lv;
 };
 
-template <int DT, int TAPS, int NTN, int NTC, int DG, int TH>
+template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R>
 struct WgradCfg {
   static constexpr int CE = Elt<DT>::CE;
   static constexpr int SPP = 32 / CE;            // 16-B slots per pixel per 32-channel tile
@@ -49,12 +53,13 @@ struct WgradCfg {
   static constexpr int HALO = TAPS == 9 ? 1 : 0;
   static constexpr int HR = TH + 2 * HALO, HC = 16 + 2 * HALO;
   static constexpr int NPOS = TH * 16, NHPOS = HR * HC;
-  static constexpr int R = DG + 1;               // dy ring slots
   static constexpr int DY_SLOTS = NTN * NPOS * SPP;   // one dy frame
   static constexpr int X_SLOTS = NTC * NHPOS * SPP;   // one x halo tile
-  static constexpr int DY_BYTES = DY_SLOTS * 16, X_BYTES = X_SLOTS * 16;
-  static constexpr int LDS_BYTES = 2 * X_BYTES + R * DY_BYTES;
+  static constexpr int DWP = (DY_SLOTS + 63) / 64, XWP = (X_SLOTS + 63) / 64;  // 64-slot wave-pieces
+  static constexpr int DY_BYTES = DWP * 1024, X_BYTES = XWP * 1024;
+  static constexpr int LDS_BYTES = R * X_BYTES + 2 * DY_BYTES;
   static_assert(NTN * NTC * DG == 8, "one (n-tile, c-tile, dt) group per wave");
+  static_assert(R > DG, "the ring holds the DG frames of a stage plus the one in flight");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -69,13 +74,14 @@ __device__ __forceinline__ u32x4 join(const u32x2& lo, const u32x2& hi) {
   return v;
 }
 
-template <int DT, int TAPS, int NTN, int NTC, int DG, int TH>
-__global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
-  typedef WgradCfg<DT, TAPS, NTN, NTC, DG, TH> C;
+// (the body is a __device__ function: the buffer-descriptor type it uses exists only in device compilation)
+template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R>
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
+  typedef WgradCfg<DT, TAPS, NTN, NTC, DG, TH, R> C;
   constexpr int CE = C::CE, ES = 16 / CE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const xbase = smem;
-  char* const dybase = smem + 2 * C::X_BYTES;
+  char* const dybase = smem + R * C::X_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = wv % NTN, ct = (wv / NTN) % NTC, dg = wv / (NTN * NTC);
@@ -91,12 +97,14 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
   const int cb = q, nb = g % a.n_blocks, db = g / a.n_blocks;
   const int n_base = nb * NTN * 32, c_base = cb * NTC * 32, dt0 = db * DG;
   const int dt_live = min(DG, a.kt - dt0);      // temporal taps of this group that exist
-  const int nfr = a.t_out + dt_live - 1;        // input frames per tile: t = dt0 .. dt0 + nfr - 1
+  const int nxf = a.t_out + dt_live - 1;        // x frames per tile: t = dt0 .. dt0 + nxf - 1
 
   const int per = (a.ntiles + a.psplit - 1) / a.psplit;
   const int tile_begin = ps * per;
   const int tile_end = min(a.ntiles, tile_begin + per);
-  const int S = max(0, tile_end - tile_begin) * nfr;
+  const int ntile = max(0, tile_end - tile_begin);
+  const int S = ntile * a.t_out;   // stages (tile, fo)
+  const int QT = ntile * nxf;      // x tile loads, in the order they are needed
 
   f32x16 acc[TAPS];
 #pragma unroll
@@ -106,82 +114,113 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
 
   const bool wave_live = (n_base + nt * 32 < a.c_out) && (c_base + ct * 32 < a.c_in) && (dg < dt_live);
 
-  // ---- DMA side: per-tile context (recomputed only when the issued stage enters a new pixel tile) ---
-  constexpr int NDY = (C::DY_SLOTS + 511) / 512, NXP = (C::X_SLOTS + 511) / 512, NPIECE = NDY + NXP;
-  int dyo[NDY], xo[NXP];  // byte offsets inside a frame; -1 zero page; -2 no slot
-  const char* dy_tile = a.dy;  // frame 0 of the tile's clip in dy / frame dt0 in x
-  const char* x_tile = a.x;
+  // ---- staging side.  The x loads run ahead of the dy loads (up to R frames, possibly into the next pixel
+  // tile), so each stream keeps its own tile context: per-lane offsets inside a frame, frame 0, frame stride.
+  constexpr int NDY = (C::DWP + 7) / 8, NXP = (C::XWP + 7) / 8;  // wave w copies wave-pieces w, w+8, ...
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned dyo[NDY], xo[NXP];
+  const char* dy_frame0 = a.dy; const char* x_frame0 = a.x;
   long long dy_fstride = 0, x_fstride = 0;
-  int i_tile = -1, i_fi = 0;  // tile / frame index of the NEXT stage to issue
+  int xi_q = 0, xi_tile = tile_begin - 1, xi_f = nxf;        // next x load: index, its tile, its frame in the tile
+  int di_tile = tile_begin - 1, di_fo = a.t_out;             // next dy load
   const int lds_wave_off = wv * 1024;
-  auto enter_tile = [&](int tile) {
-    int lvl = 0;
+  auto tile_geom = [&](int tile, int& lvl, int& b, int& h0, int& w0) {
+    lvl = 0;
 #pragma unroll
     for (int l = 1; l < SFVOS_MAX_LEVELS; ++l)
       if (l < a.lv.n && tile >= a.lv.tile_begin[l]) lvl = l;
-    const int H = a.lv.H[lvl], W = a.lv.W[lvl];
-    const long long HWp = (long long)H * W;
     int k = tile - a.lv.tile_begin[lvl];
     const int tw = k % a.lv.tiles_w[lvl]; k /= a.lv.tiles_w[lvl];
     const int th = k % a.lv.tiles_h[lvl]; k /= a.lv.tiles_h[lvl];
-    const int b = k;
-    const int h0 = th * TH, w0 = tw * 16;
-    dy_fstride = HWp * a.ld_y * ES;
+    b = k; h0 = th * TH; w0 = tw * 16;
+  };
+  auto enter_tile_x = [&](int tile) {
+    int lvl, b, h0, w0;
+    tile_geom(tile, lvl, b, h0, w0);
+    const int H = a.lv.H[lvl], W = a.lv.W[lvl];
+    const long long HWp = (long long)H * W;
     x_fstride = HWp * a.ld_x * ES;
-    dy_tile = a.dy + (a.lv.ypos[lvl] + (long long)b * a.t_out * HWp) * a.ld_y * ES;
-    x_tile = a.x + (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset + dt0) * HWp) * a.ld_x * ES;
-#pragma unroll
-    for (int it = 0; it < NDY; ++it) {
-      const int sl = it * 512 + tid;
-      const int j = sl % C::SPP, pos = (sl / C::SPP) % C::NPOS, tnt = sl / (C::SPP * C::NPOS);
-      const int h = h0 + pos / 16, w = w0 + pos % 16, n = n_base + tnt * 32;
-      const bool ok = h < H && w < W && n < a.c_out;
-      dyo[it] = sl >= C::DY_SLOTS ? -2 : (ok ? (int)((((long long)h * W + w) * a.ld_y + n + j * CE) * ES) : -1);
-    }
+    x_frame0 = a.x + (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset + dt0) * HWp) * a.ld_x * ES;
 #pragma unroll
     for (int it = 0; it < NXP; ++it) {
       const int sl = it * 512 + tid;
       const int j = sl % C::SPP, hp = (sl / C::SPP) % C::NHPOS, tct = sl / (C::SPP * C::NHPOS);
       const int h = h0 + hp / C::HC - C::HALO, w = w0 + hp % C::HC - C::HALO, c = c_base + tct * 32;
-      const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W && c < a.c_in;
-      xo[it] = sl >= C::X_SLOTS ? -2 : (ok ? (int)((((long long)h * W + w) * a.ld_x + c + j * CE) * ES) : -1);
+      const bool ok = sl < C::X_SLOTS && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W && c < a.c_in;
+      xo[it] = ok ? (unsigned)((((long long)h * W + w) * a.ld_x + c + j * CE) * ES) : OOB;
     }
   };
-  // scalars of the copy for stage s (x[t = dt0 + fi] halo tile -> x buffer s&1, dy frame fi -> ring slot s%R)
-  struct Dma { const char* dyf; const char* xf; char* dyb; char* xb; bool on, dy_ok, x_ok; };
-  auto prep = [&](Dma& d, int s) {
-    if (i_tile < 0 || i_fi == nfr) {
-      i_tile = i_tile < 0 ? tile_begin : i_tile + 1;
-      i_fi = 0;
-      enter_tile(i_tile);
+  auto enter_tile_dy = [&](int tile) {
+    int lvl, b, h0, w0;
+    tile_geom(tile, lvl, b, h0, w0);
+    const int H = a.lv.H[lvl], W = a.lv.W[lvl];
+    const long long HWp = (long long)H * W;
+    dy_fstride = HWp * a.ld_y * ES;
+    dy_frame0 = a.dy + (a.lv.ypos[lvl] + (long long)b * a.t_out * HWp) * a.ld_y * ES;
+#pragma unroll
+    for (int it = 0; it < NDY; ++it) {
+      const int sl = it * 512 + tid;
+      const int j = sl % C::SPP, pos = (sl / C::SPP) % C::NPOS, tnt = sl / (C::SPP * C::NPOS);
+      const int h = h0 + pos / 16, w = w0 + pos % 16, n = n_base + tnt * 32;
+      const bool ok = sl < C::DY_SLOTS && h < H && w < W && n < a.c_out;
+      dyo[it] = ok ? (unsigned)((((long long)h * W + w) * a.ld_y + n + j * CE) * ES) : OOB;
     }
-    d.on = true;
-    d.dy_ok = i_fi < a.t_out;
-    d.x_ok = dt0 + i_fi < a.t_in;
-    d.dyf = dy_tile + (long long)i_fi * dy_fstride;
-    d.xf = x_tile + (long long)i_fi * x_fstride;
-    d.xb = xbase + (s & 1) * C::X_BYTES + lds_wave_off;
-    d.dyb = dybase + (s % C::R) * C::DY_BYTES + lds_wave_off;
-    ++i_fi;
   };
-  auto piece = [&](const Dma& d, int p) {
-    if (!d.on) return;
-    if (p < NDY) {
-      if (dyo[p] > -2) glds16((d.dy_ok && dyo[p] >= 0) ? d.dyf + dyo[p] : a.zeros, d.dyb + p * 8192);
-    } else {
-      const int u = p - NDY;
-      if (xo[u] > -2) glds16((d.x_ok && xo[u] >= 0) ? d.xf + xo[u] : a.zeros, d.xb + u * 8192);
+  struct Copy { const char* src; char* dst; int rec; };
+  auto begin_x = [&](Copy& c) {  // next x tile of the load order -> ring slot xi_q % R
+    if (xi_f == nxf) { xi_f = 0; enter_tile_x(++xi_tile); }
+    c.src = x_frame0 + (long long)xi_f * x_fstride;
+    c.rec = (int)x_fstride;
+    c.dst = xbase + (xi_q % R) * C::X_BYTES + lds_wave_off;
+    ++xi_f; ++xi_q;
+  };
+  auto begin_dy = [&](Copy& c, int s) {  // dy frame of stage s -> buffer s & 1
+    if (di_fo == a.t_out) { di_fo = 0; enter_tile_dy(++di_tile); }
+    c.src = dy_frame0 + (long long)di_fo * dy_fstride;
+    c.rec = (int)dy_fstride;
+    c.dst = dybase + (s & 1) * C::DY_BYTES + lds_wave_off;
+    ++di_fo;
+  };
+  auto x_piece = [&](const Copy& c, int p) {
+    if (p * 8 + wv < C::XWP) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)c.src, 0, c.rec, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (SFVOS_LDS void*)(c.dst + p * 8192), 16, xo[p], 0, 0, 0);
     }
+  };
+  auto dy_piece = [&](const Copy& c, int p) {
+    if (p * 8 + wv < C::DWP) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)c.src, 0, c.rec, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (SFVOS_LDS void*)(c.dst + p * 8192), 16, dyo[p], 0, 0, 0);
+    }
+  };
+  auto load_x_now = [&]() {
+    Copy c;
+    begin_x(c);
+#pragma unroll
+    for (int p = 0; p < NXP; ++p) x_piece(c, p);
   };
 
-  // ---- compute side --------------------------------------------------------------------------------
-  auto compute = [&](int s, bool live, const Dma& d) {
-    // this wave pairs x[t] with dy[t - dt0 - dg], which entered the ring dg stages ago
-    const char* dyb = dybase + ((s - dg + C::R) % C::R) * C::DY_BYTES + nt * (C::NPOS * C::ROWB);
-    const char* xb = xbase + (s & 1) * C::X_BYTES + ct * (C::NHPOS * C::ROWB);
-    if (!live) {  // nothing to multiply at this stage (frame outside this wave's tap): just feed the DMA
+  // ---- compute side: stage s multiplies dy buffer s&1 with the x frame in ring slot (q0 + dg) % R; while it
+  // runs, up to two more x tiles (nx) and the next dy frame (ndy) are copied, piece by piece between MFMA groups.
+  constexpr int TROWS = TAPS == 9 ? 3 : 1, TCOLS = TAPS == 9 ? 3 : 1;
+  constexpr int NSTEP = TH * TROWS;
+  static_assert(2 * NXP + NDY + 2 <= NSTEP || DT != SFVOS_BF16, "the copies of a stage must fit between its MFMA steps");
+  auto compute = [&](int s, int q0, int nx, bool ndy) {
+    const char* dyb = dybase + (s & 1) * C::DY_BYTES + nt * (C::NPOS * C::ROWB);
+    const char* xb = xbase + ((q0 + dg) % R) * C::X_BYTES + ct * (C::NHPOS * C::ROWB);
+    Copy cx, cd;
+    // copy schedule by step: [0] begin x#1, [0..NXP) its pieces, [NXP] begin x#2, then its pieces, then dy
+    auto copies = [&](int step) {
+      if (step == 0 && nx > 0) begin_x(cx);
+      if (step < NXP) { if (nx > 0) x_piece(cx, step); return; }
+      if (step == NXP && nx > 1) begin_x(cx);
+      if (step < 2 * NXP) { if (nx > 1) x_piece(cx, step - NXP); return; }
+      if (step == 2 * NXP && ndy) begin_dy(cd, s + 1);
+      if (step < 2 * NXP + NDY) { if (ndy) dy_piece(cd, step - 2 * NXP); return; }
+    };
+    if (!wave_live) {  // nothing to multiply (tap / channel tile past the tensor): just feed the copies
 #pragma unroll
-      for (int p = 0; p < NPIECE; ++p) piece(d, p);
+      for (int step = 0; step < 2 * NXP + NDY; ++step) copies(step);
       return;
     }
     if constexpr (DT == SFVOS_BF16) {
@@ -190,12 +229,9 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
       const int lane_off = (8 * (gq >> 1) + qq) * C::ROWB + (16 * (gq & 1) + 4 * pp) * 2;
       const char* dyl = dyb + lane_off;  // every read below adds a compile-time constant (ds_read offset field)
       const char* xl = xb + lane_off;
-      constexpr int TROWS = TAPS == 9 ? 3 : 1, TCOLS = TAPS == 9 ? 3 : 1;
       // step = (ty, dh): one A fragment per ty, TCOLS B fragments per step; a PD-deep register pipeline
-      // reads the fragments of step+PD-1 while this step's MFMAs run (order pinned with sched_barrier);
-      // the DMA pieces of the next stage are issued between the MFMA groups.
-      constexpr int PD = 3, NSTEP = TH * TROWS;
-      constexpr int PPS = (NPIECE + NSTEP - 1) / NSTEP;
+      // reads the fragments of step+PD-1 while this step's MFMAs run (order pinned with sched_barrier)
+      constexpr int PD = 3;
       u32x2 ar[PD][2], br[PD][TCOLS][2];
       auto load = [&](int step, int buf) {
         const int ty = step / TROWS, dh = step % TROWS;
@@ -221,13 +257,12 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
         for (int dw = 0; dw < TCOLS; ++dw)
           Mma<SFVOS_BF16>::run(acc[dh * TCOLS + dw], av, join(br[step % PD][dw][0], br[step % PD][dw][1]));
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < PPS; ++u)
-          if (step * PPS + u < NPIECE) piece(d, step * PPS + u);
+        copies(step);
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
 #pragma unroll
-      for (int p = 0; p < NPIECE; ++p) piece(d, p);
+      for (int step = 0; step < 2 * NXP + NDY; ++step) copies(step);
 #pragma unroll
       for (int ty = 0; ty < TH; ++ty) {
 #pragma unroll
@@ -244,21 +279,29 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
     }
   };
 
+  // ---- main loop ----------------------------------------------------------------------------------------
   if (S > 0) {
-    Dma d0;
-    prep(d0, 0);
+    Copy c;
+    begin_dy(c, 0);
 #pragma unroll
-    for (int p = 0; p < NPIECE; ++p) piece(d0, p);
+    for (int p = 0; p < NDY; ++p) dy_piece(c, p);
   }
-  int c_fi = 0;  // frame index of the stage being computed
+  int q0 = 0, fo = 0;  // first x load of the stage (tile_local * nxf + fo), dy frame of the stage
   for (int s = 0; s < S; ++s) {
+    const int need = q0 + dt_live - 1;  // last x load this stage reads
+    if (xi_q <= need) {
+      // not yet copied (start of the sweep, or a tile boundary the ring could not prefetch across): every wave
+      // is done with the previous stage after this barrier, so the slots of its frames may be overwritten
+      if (s > 0) __syncthreads();
+      while (xi_q <= need) load_x_now();
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    Dma d; d.on = false;
-    if (s + 1 < S) prep(d, s + 1);
-    const int fo = c_fi - dg;  // dy frame this wave pairs with x[t] at this stage
-    compute(s, wave_live && fo >= 0 && fo < a.t_out, d);
-    if (++c_fi == nfr) c_fi = 0;
+    // loads q < q0 + R overwrite frames that no stage >= s reads
+    const int nx = max(0, min(2, min(QT, q0 + R) - xi_q));
+    compute(s, q0, nx, s + 1 < S);
+    ++q0;
+    if (++fo == a.t_out) { fo = 0; q0 += dt_live - 1; }
   }
 
   // slab[ps][n][dt][tap][c]
@@ -272,6 +315,11 @@ __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
         a.slab[((((long long)ps * a.c_out + n) * a.kt + dt) * TAPS + tap) * a.c_in + c] = acc[tap][e];
       }
   }
+}
+
+template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R>
+__global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
+  wgrad_body<DT, TAPS, NTN, NTC, DG, TH, R>(a);
 }
 
 // grad_w[n][c][dt][tap] (=|+=) sum_ps slab[ps][n][dt][tap][c]
@@ -306,6 +354,17 @@ struct WgradPlan {
   int n_blocks, c_blocks, dt_blocks, psplit, t_out, ntiles;
   WgradLevels lv;
 };
+
+static int wgrad_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+           prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return cus;
+}
 
 static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
   SFVOS_REQUIRE(d != nullptr, "wgrad: null desc");
@@ -354,7 +413,22 @@ static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
   p->dt_blocks = ceil_div(d->kt, p->DG);
   p->ntiles = (int)tiles;
   const int col_blocks = p->n_blocks * p->c_blocks * p->dt_blocks;
-  int ps = ceil_div(768, col_blocks);  // ~3 workgroups per CU over the launch
+  // Pixel split (split-K): workgroup ids are dealt round-robin over the 8 XCDs and the kernel keeps the pixel split
+  // ps on XCD ps % 8, so an XCD runs col_blocks * psplit/8 workgroups, one per CU at a time.  Choose psplit = 8 m
+  // so that this fills k whole rounds of the XCD's CUs, trading idle CUs in the last round (want m large) against
+  // slab traffic (one fp32 slab written and re-read per split: want m small).
+  const int cus_xcd = wgrad_cus() / 8 > 0 ? wgrad_cus() / 8 : 32;
+  const double t_mma = 2.0 * d->c_in * d->c_out * d->kt * d->taps * (double)p->t_out * px * d->batch / 1.0e15;
+  const double t_slab = 2.0 * 4.0 * d->c_out * d->c_in * d->kt * d->taps / 3.0e12;  // per split: write + read
+  int ps = 8;
+  double best = 1e30;
+  for (int k = 1; k <= 4; ++k) {
+    const int m = (cus_xcd * k) / col_blocks;
+    if (m < 1) continue;
+    const double cost = t_mma * (double)(cus_xcd * k) / (double)(col_blocks * m) + 8.0 * m * t_slab;
+    if (cost < best) { best = cost; ps = 8 * m; }
+  }
+  if (const char* ov = getenv("SFVOS_WGRAD_SPLIT")) ps = atoi(ov) > 0 ? atoi(ov) : ps;  // tuning aid
   if (ps > p->ntiles) ps = p->ntiles;
   if (ps < 1) ps = 1;
   const int per = ceil_div(p->ntiles, ps);  // no empty splits
@@ -362,10 +436,10 @@ static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
   return SFVOS_OK;
 }
 
-template <int DT, int TAPS, int NTN, int NTC, int DG, int TH>
+template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R>
 static int launch_wgrad(const WgradArgs& a, long long grid, hipStream_t stream) {
-  typedef WgradCfg<DT, TAPS, NTN, NTC, DG, TH> C;
-  auto kern = wgrad_kernel<DT, TAPS, NTN, NTC, DG, TH>;
+  typedef WgradCfg<DT, TAPS, NTN, NTC, DG, TH, R> C;
+  auto kern = wgrad_kernel<DT, TAPS, NTN, NTC, DG, TH, R>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -408,10 +482,11 @@ extern "C" int sfvos_conv3d_wgrad(const sfvos_conv_desc* d, const void* x, const
   hipStream_t s = (hipStream_t)stream;
   const bool bf = d->dtype == SFVOS_BF16;
   switch (p.cfg) {
-    case 0: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 1, 2, 4, 8>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 1, 2, 4, 4>(a, grid, s); break;
-    case 1: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 2, 2, 2, 8>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 2, 2, 2, 4>(a, grid, s); break;
-    case 2: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 1, 1, 8, 8>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 1, 1, 8, 4>(a, grid, s); break;
-    default: rc = bf ? launch_wgrad<SFVOS_BF16, 1, 2, 1, 4, 8>(a, grid, s) : launch_wgrad<SFVOS_F32, 1, 2, 1, 4, 4>(a, grid, s); break;
+    // last template argument: x ring slots (R >= 2 DG lets the ring prefetch across pixel-tile boundaries)
+    case 0: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 1, 2, 4, 8, 5>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 1, 2, 4, 4, 5>(a, grid, s); break;
+    case 1: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 2, 2, 2, 8, 5>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 2, 2, 2, 4, 4>(a, grid, s); break;
+    case 2: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 1, 1, 8, 8, 11>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 1, 1, 8, 4, 10>(a, grid, s); break;
+    default: rc = bf ? launch_wgrad<SFVOS_BF16, 1, 2, 1, 4, 8, 8>(a, grid, s) : launch_wgrad<SFVOS_F32, 1, 2, 1, 4, 4, 8>(a, grid, s); break;
   }
   if (rc != SFVOS_OK) return rc;
   const long long total = (long long)d->c_out * d->c_in * d->kt * d->taps;
