@@ -373,6 +373,25 @@ class SlowFastLayers(nn.Module):
 
         # -- phase 1 (current stream): decide what runs, allocate every buffer / workspace, pack dgrad images
         any_param = any(need_param.values())
+        # optional gradient sink (FusedSGD.attach): parameter gradients are written (first backward after
+        # zero_grad()) or accumulated (later ones) straight into its flat buffer by the kernels that produce
+        # them, and autograd gets None for them -- no temporary + `grad += tmp` launch per parameter.
+        sink = getattr(self, '_grad_sink', None)
+        sink_mode = sink.begin_direct(dev) if sink is not None else 0   # 0 off, 1 overwrite, 2 accumulate
+        sink = sink if sink_mode else None
+        sacc = 1 if sink_mode == 2 else 0
+        direct = set()
+
+        def sink_view(pname):
+            mod, attr = pname.split('.')
+            return sink.view_of(getattr(self, mod)._parameters[attr]) if sink is not None else None
+
+        def gout(pname, shape, ok=True):
+            t = sink_view(pname) if ok else None
+            if t is None:
+                return torch.empty(shape, dtype=torch.float32, device=dev)
+            direct.add(pname)
+            return t
         todo = []
         written = set()
         keepalive = []
@@ -391,12 +410,13 @@ class SlowFastLayers(nn.Module):
             rows = lib.sfvos_bn_bwd_rows(ctypes.byref(lv))
             w = dict(l=l, lv=lv, rows=rows, need_in=need_in, need_w=need_w, need_b=need_b,
                      part=torch.empty((rows, 2, l.c_out), dtype=torch.float32, device=dev),
-                     dgamma=torch.empty(l.c_out, dtype=torch.float32, device=dev),
-                     dbeta=torch.empty(l.c_out, dtype=torch.float32, device=dev),
+                     # dgamma and dbeta leave one kernel with one accumulate flag: both direct or neither
+                     dgamma=gout(l.bn + '.weight', (l.c_out,), sink_view(l.bn + '.bias') is not None),
+                     dbeta=gout(l.bn + '.bias', (l.c_out,), sink_view(l.bn + '.weight') is not None),
                      dx=torch.empty((_lv_total(lv), l.c_out), dtype=tdt, device=dev))
             if need_b:
                 w['bpart'] = torch.empty((rows, l.c_out), dtype=torch.float32, device=dev)
-                w['db'] = torch.empty(l.c_out, dtype=torch.float32, device=dev)
+                w['db'] = gout(l.conv + '.bias', (l.c_out,))
             sname, t_alloc, t_off = self._src_window(l, state.slow_offset)
             w['src'] = bufs[sname]
             if need_w:
@@ -406,7 +426,7 @@ class SlowFastLayers(nn.Module):
                     _lib.check(-1, 'sfvos_conv3d_wgrad_workspace_bytes')
                 w['wd'] = d
                 w['ws'] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                w['gw'] = torch.empty(conv.weight.shape, dtype=torch.float32, device=dev)
+                w['gw'] = gout(l.conv + '.weight', tuple(conv.weight.shape))
             if need_in:
                 if l.src not in gb:
                     galloc(l.src)
@@ -445,8 +465,8 @@ class SlowFastLayers(nn.Module):
                           ctypes.byref(lv), l.c_out, _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), _ptr(cf[0, _MEAN]),
                           _ptr(cf[0, _RSTD]), cs, 1 if l.relu else 0, _ptr(w['part']), st)
                 _lib.call('sfvos_bn_bwd_finalize', _ptr(w['part']), ctypes.byref(lv), _ptr(bn.weight.detach()),
-                          _ptr(cf[0, _MEAN]), _ptr(cf[0, _RSTD]), cs, l.c_out, 1 if state.train else 0, 0,
-                          _ptr(w['dgamma']), _ptr(w['dbeta']), _ptr(cf[0, _CA]), _ptr(cf[0, _CB]), _ptr(cf[0, _CK]), st)
+                          _ptr(cf[0, _MEAN]), _ptr(cf[0, _RSTD]), cs, l.c_out, 1 if state.train else 0,
+                          sacc if (l.bn + '.weight') in direct else 0, _ptr(w['dgamma']), _ptr(w['dbeta']), _ptr(cf[0, _CA]), _ptr(cf[0, _CB]), _ptr(cf[0, _CK]), st)
                 grads[l.bn + '.weight'], grads[l.bn + '.bias'] = w['dgamma'], w['dbeta']
                 _lib.call('sfvos_bn_bwd_apply', _ptr(dy, l.dst_off), dy.shape[-1], _ptr(raw), l.c_out, _ptr(dx),
                           l.c_out, dt_id, ctypes.byref(lv), l.c_out, _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), cs,
@@ -454,7 +474,8 @@ class SlowFastLayers(nn.Module):
                           _ptr(w['bpart']) if w['need_b'] else None, st)
                 treg.__exit__(None, None, None)
                 if w['need_b']:
-                    _lib.call('sfvos_reduce_rows', _ptr(w['bpart']), rows, l.c_out, _ptr(w['db']), 0, st)
+                    _lib.call('sfvos_reduce_rows', _ptr(w['bpart']), rows, l.c_out, _ptr(w['db']),
+                              sacc if (l.conv + '.bias') in direct else 0, st)
                     grads[l.conv + '.bias'] = w['db']
                 if w['need_in']:  # data gradient first: the other pathway may be waiting for it
                     with self._t('conv_dgrad', l.name):
@@ -466,11 +487,15 @@ class SlowFastLayers(nn.Module):
                 if w['need_w']:
                     with self._t('wgrad', l.name):
                         _lib.call('sfvos_conv3d_wgrad', ctypes.byref(w['wd']), _ptr(w['src']), _ptr(dx), _ptr(w['gw']),
-                                  0, _ptr(w['ws']), _ptr(zeros), st)
+                                  sacc if (l.conv + '.weight') in direct else 0, _ptr(w['ws']), _ptr(zeros), st)
                     grads[l.conv + '.weight'] = w['gw']
         if side is not None:
             main.wait_stream(side)
         del keepalive  # workspaces are released only after the join
+        for n in direct:  # already in the optimiser's buffer: nothing for autograd to accumulate
+            grads[n] = None
+        if sink is not None:
+            sink.end_direct()
         return grads, gb
 
     # ------------------------------------------------------------------ input layout

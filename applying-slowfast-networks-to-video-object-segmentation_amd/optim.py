@@ -40,10 +40,40 @@ class FusedSGD(torch.optim.Optimizer):
                 p.grad = self.flat_grad[off:off + k].view_as(p)
                 off += k
         self._steps = 0
+        self._views = {id(p): p.grad for p in params}
+        self._clean = False  # True between zero_grad() and the first gradient written after it
+
+    def attach(self, module):
+        """Let `module` (a SlowFastLayers) write its parameter gradients straight into the flat gradient buffer
+        (overwrite on the first backward after zero_grad(), accumulate in place on later ones): no per-parameter
+        temporaries and no `grad += tmp` launches.  dgamma/dbeta of a BatchNorm share one kernel, so both or neither
+        of them must be FusedSGD parameters (always true for SlowFastLayers.parameters())."""
+        module._grad_sink = self
+        return self
+
+    # -- gradient-sink protocol used by SlowFastLayers._engine_backward
+    def begin_direct(self, device):
+        """0: not available; 1: overwrite (first backward after zero_grad()); 2: accumulate."""
+        if device != self.flat_grad.device:
+            return 0
+        for p in self._params:  # someone re-pointed a .grad: fall back to autograd accumulation
+            if p.grad is not self._views[id(p)]:
+                return 0
+        return 1 if self._clean else 2
+
+    def view_of(self, p):
+        return self._views.get(id(p))
+
+    def end_direct(self):
+        self._clean = False
 
     def zero_grad(self, set_to_none=False):
         # grads are views of flat_grad: zero in place, never detach them
         self.flat_grad.zero_()
+        for p in self._params:
+            if p.grad is not self._views[id(p)]:
+                p.grad = self._views[id(p)]
+        self._clean = True
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -36,6 +36,8 @@ def parse():
                          'durations, the default here); 2 = slow pathway on a side stream (module default, ~5 %% '
                          'more clips/s, but concurrent kernels stretch each other\'s measured duration)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-grad-sink', action='store_true',
+                    help='let autograd accumulate parameter gradients from temporaries (A/B of FusedSGD.attach)')
     ap.add_argument('--cpu-threads', type=int, default=0)
     return ap.parse_args()
 
@@ -97,6 +99,8 @@ def main():
     model.train()
     model.n_streams = args.streams
     opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    if not args.no_grad_sink:
+        opt.attach(model)   # kernels write parameter gradients straight into the flat gradient buffer
     bucket = GradBucket(opt.flat_grad)
     tdt = torch.bfloat16 if args.precision == 'bf16' else torch.float32
     pyr = davis_pyramid()

@@ -47,7 +47,7 @@ def _check_against_fixture(sp, fp, levels, g, use_fused_sgd):
     # ---- two accumulated training clips + one SGD step (model.py:369-374, train.py:80)
     m.train()
     params = list(m.parameters())
-    opt = FusedSGD(params, lr=1e-3, momentum=0.9, weight_decay=1e-4) if use_fused_sgd else \
+    opt = FusedSGD(params, lr=1e-3, momentum=0.9, weight_decay=1e-4).attach(m) if use_fused_sgd else \
         torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=1e-4)
     opt.zero_grad()
     for clip in (0, 1):
@@ -153,6 +153,33 @@ def test_frozen_parameters_and_no_grad():
     with torch.no_grad():
         out = m.temporally_enhance_features(slow, fast)
     assert not out['0'].requires_grad
+
+
+@pytest.mark.parametrize('freeze', [None, 'bn_s2.weight'])
+def test_gradient_sink_matches_autograd_accumulation(freeze):
+    """FusedSGD.attach(): gradients written / accumulated straight into the flat buffer by the kernels equal
+    the ones autograd accumulates from temporaries, over two clips (overwrite, then accumulate), also when a
+    BatchNorm has only one of its two parameters in the optimiser."""
+    from sfvos_amd import FusedSGD
+    flats = []
+    for attach in (True, False):
+        m, dev = build(3, 7, 'fp32')
+        m.train()
+        if freeze:
+            mod, attr = freeze.split('.')
+            getattr(m, mod)._parameters[attr].requires_grad = False
+        opt = FusedSGD(m.parameters())
+        if attach:
+            opt.attach(m)
+        opt.zero_grad()
+        for clip in (0, 1):
+            slow, fast = clip_inputs(3, 7, SMALL_LEVELS, clip, dev)
+            proxy_loss(m.temporally_enhance_features(slow, fast)).backward()
+        flats.append(opt.flat_grad.clone())
+        if attach:  # the sink must have been used: autograd saw no gradient for the conv weights
+            assert m._grad_sink is opt and not opt._clean
+    scale = float(flats[1].abs().max())
+    assert scale > 0 and float((flats[0] - flats[1]).abs().max()) <= 1e-6 * scale
 
 
 def test_cpu_tensors_are_refused():
