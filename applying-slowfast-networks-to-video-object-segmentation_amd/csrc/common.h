@@ -63,6 +63,9 @@ __device__ __forceinline__ u32x4 lds_read16(const void* p) { return *(const u32x
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// lateral.hip: dedicated kernel for the lateral (k x 1 x 1) data gradient; -1 = shape not covered
+int lateral_dgrad_try(const sfvos_conv_desc* d, const void* x, const void* w_packed, void* y, hipStream_t stream);
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

@@ -1083,6 +1083,10 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
   SFVOS_REQUIRE(!(stat_part && d->accumulate), "conv: statistics are those of the conv result; not available with accumulate");
   SFVOS_REQUIRE(d->ld_y % (d->dtype == SFVOS_BF16 ? 8 : 4) == 0, "conv: ld_y %d must be a multiple of a 16-byte chunk", d->ld_y);
   SFVOS_REQUIRE(!(d->taps == 1 && p.family == 2), "conv: 1x1 conv with c_out > 64 has no kernel instance");
+  if (!bias && !stat_part && d->taps == 1 && !getenv("SFVOS_NO_LATERAL_KERNEL")) {
+    rc = lateral_dgrad_try(d, x, w_packed, y, (hipStream_t)stream);  // lateral data gradient: its own HBM-bound kernel
+    if (rc >= 0) return rc;
+  }
   ConvArgs a;
   a.x = (const char*)x; a.wp = (const char*)w_packed; a.bias = bias; a.y = (char*)y; a.stat_part = stat_part;
   a.zeros = (const char*)zeros;

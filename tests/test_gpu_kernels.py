@@ -155,7 +155,10 @@ def test_conv3d_reads_a_frame_window_of_a_longer_clip(lib, prec):
 
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 @pytest.mark.parametrize('case', [(1, 4, [(12, 21)], 256, 192, 2, 9), (1, 13, [(10, 19), (4, 5)], 32, 32, 2, 9),
-                                  (1, 9, [(9, 16)], 32, 64, 5, 1), (1, 7, [(6, 10), (2, 3)], 256, 32, 3, 9)])
+                                  (1, 9, [(9, 16)], 32, 64, 5, 1), (1, 7, [(6, 10), (2, 3)], 256, 32, 3, 9),
+                                  # lateral data gradients with <= 3 slow frames: the dedicated bf16 kernel (lateral.hip)
+                                  (1, 7, [(9, 16), (5, 7)], 32, 64, 5, 1), (2, 12, [(6, 10), (3, 3)], 32, 64, 11, 1),
+                                  (1, 20, [(7, 9)], 32, 64, 20, 1)])
 def test_conv3d_dgrad_and_accumulate(lib, prec, case):
     B, T, shapes, cin, cout, kt, taps = case
     g = torch.Generator().manual_seed(99)
