@@ -229,6 +229,44 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
       const int lane_off = (8 * (gq >> 1) + qq) * C::ROWB + (16 * (gq & 1) + 4 * pp) * 2;
       const char* dyl = dyb + lane_off;  // every read below adds a compile-time constant (ds_read offset field)
       const char* xl = xb + lane_off;
+      if constexpr (TAPS == 9) {
+        // row walk: step = halo row rr of the x tile.  Its three column-shifted fragments are read ONCE and serve the
+        // (output row ty, vertical tap dh) pairs with ty + dh = rr -- up to 9 MFMAs on 9 different accumulators;
+        // the dy fragments of rows rr, rr-1, rr-2 stay in a 4-deep rolling buffer.  76 transposed reads per stage
+        // instead of 160.  Fragments of step rr+1 are read while the MFMAs of step rr run (pinned order).
+        constexpr int NROW = TH + 2;
+        static_assert(2 * NXP + NDY <= NROW, "the copies of a stage must fit between its row steps");
+        u32x2 ar[4][2], br[2][3][2];
+        auto load = [&](int rr) {
+          if (rr < TH) {
+            ar[rr & 3][0] = tr_read(dyl + rr * 16 * C::ROWB);
+            ar[rr & 3][1] = tr_read(dyl + (rr * 16 + 4) * C::ROWB);
+          }
+#pragma unroll
+          for (int dw = 0; dw < 3; ++dw) {
+            br[rr & 1][dw][0] = tr_read(xl + (rr * C::HC + dw) * C::ROWB);
+            br[rr & 1][dw][1] = tr_read(xl + (rr * C::HC + dw + 4) * C::ROWB);
+          }
+        };
+        load(0);
+#pragma unroll
+        for (int rr = 0; rr < NROW; ++rr) {
+          if (rr + 1 < NROW) load(rr + 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int dh = 0; dh < 3; ++dh) {
+            const int ty = rr - dh;
+            if (ty < 0 || ty >= TH) continue;
+            const u32x4 av = join(ar[ty & 3][0], ar[ty & 3][1]);
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw)
+              Mma<SFVOS_BF16>::run(acc[dh * 3 + dw], av, join(br[rr & 1][dw][0], br[rr & 1][dw][1]));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          copies(rr);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
       // step = (ty, dh): one A fragment per ty, TCOLS B fragments per step; a PD-deep register pipeline
       // reads the fragments of step+PD-1 while this step's MFMAs run (order pinned with sched_barrier)
       constexpr int PD = 3;
@@ -259,6 +297,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
         __builtin_amdgcn_sched_barrier(0);
         copies(step);
         __builtin_amdgcn_sched_barrier(0);
+      }
       }
     } else {
 #pragma unroll
