@@ -77,9 +77,9 @@ struct ConvCfg {
   static constexpr int BN = WN * NT * 32;
   static constexpr int R = TT + 1;                    // ring slots
   static constexpr int X_SLOTS = 4 * HR * HC;         // 16-B slots per ring frame
-  static constexpr int X_BYTES = ((X_SLOTS * 16 + 255) / 256) * 256;
+  static constexpr int X_BYTES = ((X_SLOTS + 63) / 64) * 1024;  // whole 64-slot wave-pieces (the tail is padding)
   static constexpr int W_SLOTS = TPS * 4 * BN;
-  static constexpr int W_BYTES = W_SLOTS * 16;
+  static constexpr int W_BYTES = ((W_SLOTS + 63) / 64) * 1024;
   static constexpr int NTG = TAPS / TPS;
   static constexpr int LDS_BYTES = R * X_BYTES + 2 * W_BYTES;
   static_assert(TAPS % TPS == 0, "tap groups must tile the taps");
@@ -88,8 +88,9 @@ struct ConvCfg {
 
 // CIN: compile-time c_in (0 = runtime).  The 256-channel instances get their own symbol, so the dominant
 // launches (fast_conv1 forward) are identifiable in a rocprofv3 kernel trace, and a constant chunk count.
-template <int DT, int TAPS, int TPS, int TT, int MT, int NT, int WS, int WN, int CIN = 0>
-__global__ __launch_bounds__(64 * WS * WN, (WS * WN) / 4) void conv3d_kernel(ConvArgs a) {
+// (the body is a __device__ function: the buffer-descriptor type it uses exists only in device compilation)
+template <int DT, int TAPS, int TPS, int TT, int MT, int NT, int WS, int WN, int CIN>
+__device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
   typedef ConvCfg<DT, TAPS, TPS, TT, MT, NT, WS, WN> C;
   typedef typename Elt<DT>::type T;
   constexpr int CE = Elt<DT>::CE, CK = 4 * CE, ES = 16 / CE;
@@ -139,58 +140,71 @@ __global__ __launch_bounds__(64 * WS * WN, (WS * WN) / 4) void conv3d_kernel(Con
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][i][q][e] = 0.f;
 
-  // ---- DMA source offsets: a thread copies the same slots of every ring frame / weight slice, so its
-  // byte offsets (relative to the frame / slice base) are computed ONCE; per stage only a base is added
-  // (keeps the VALU out of the way of the MFMA stream).
-  constexpr int NX = (C::X_SLOTS + C::NTHREADS - 1) / C::NTHREADS;
-  constexpr int NW = (C::W_SLOTS + C::NTHREADS - 1) / C::NTHREADS;
-  int xo[NX], wo[NW];  // >= 0 offset ; -1 zero page (padding) ; -2 no slot
+  // ---- staging: buffer_load ... lds with per-lane offsets fixed for the whole kernel (see conv3d_fs_kernel):
+  // padding pixels / frames outside the clip are zero-filled by the descriptor's range check.  Pixel-major halo
+  // image, slot = (row*HC + col)*4 + (chunk ^ ((col>>2)&3)): four consecutive lanes copy one pixel's 64-byte
+  // run (coalesced) and the 16 lanes of a ds_read_b128 group still cover all 64 banks.
+  constexpr int XWP = (C::X_SLOTS + 63) / 64, WWP = (C::W_SLOTS + 63) / 64;  // 64-slot wave-pieces
+  constexpr int NWV = C::NWAVES;
+  constexpr int NX = (XWP + NWV - 1) / NWV, NW = (WWP + NWV - 1) / NWV;
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned xo[NX], wo[NW];
 #pragma unroll
   for (int it = 0; it < NX; ++it) {
     const int sl = it * C::NTHREADS + tid;
-    const int col = sl % C::HC, rowj = sl / C::HC, row = rowj % C::HR, j = rowj / C::HR;
+    const int cq = sl & 3, rc = sl >> 2, col = rc % C::HC, row = rc / C::HC;
+    const int j = cq ^ ((col >> 2) & 3);
     const int h = h0 + row - C::HALO, w = w0 + col - C::HALO;
-    const bool ok = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
-    xo[it] = sl >= C::X_SLOTS ? -2 : (ok ? (int)((((long long)h * W + w) * a.ld_x + j * CE) * ES) : -1);
+    const bool ok = sl < C::X_SLOTS && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+    xo[it] = ok ? (unsigned)((((long long)h * W + w) * a.ld_x + j * CE) * ES) : OOB;
   }
+  int xsw[2][C::HALO ? 3 : 1];  // lane part of an A-fragment address: k-step st, column shift dw
+#pragma unroll
+  for (int st = 0; st < 2; ++st)
+#pragma unroll
+    for (int dw = 0; dw < (C::HALO ? 3 : 1); ++dw)
+      xsw[st][dw] = ((r + dw) * 4 + ((2 * st + hh) ^ (((r + dw) >> 2) & 3))) * 16;
 #pragma unroll
   for (int it = 0; it < NW; ++it) {
     const int sl = it * C::NTHREADS + tid;
     const int tj = sl / C::BN, n = sl - tj * C::BN;  // tj = tap_local*4 + chunk
-    wo[it] = (sl < C::W_SLOTS && n0 + n < a.c_out) ? (tj * a.c_out + n) * 16 : -2;
+    wo[it] = (sl < C::W_SLOTS && n0 + n < a.c_out) ? (unsigned)((tj * a.c_out + n) * 16) : OOB;
   }
-  const int lds_wave_off = wv * 1024;  // (sl - lane) * 16 = it * NTHREADS * 16 + wave * 1024
+  const int lds_wave_off = wv * 1024;
+  const int frame_bytes = (int)(HWp * a.ld_x * ES);
 
-  // ---- DMA descriptors: the scalars of a copy are prepared at stage start; the copy itself is issued
-  // piece by piece (one global_load_lds wave-instruction per piece) between the MFMA groups of the
-  // stage, so its address arithmetic runs in the shadow of the matrix pipe instead of in front of it.
   struct Dma {
-    const char* xsrc; char* xb; bool do_x, t_ok;
-    const char* wsrc; char* wb; bool do_w;
+    const char* xsrc; char* xb; int xrec; bool do_x;
+    const char* wsrc; char* wb; int wrec; bool do_w;
   };
   constexpr int NPIECE = NX + NW;
   auto wrap = [](int sl) { return sl >= C::R ? sl - C::R : sl; };
   auto prep_frame = [&](Dma& d, int cc, int i, int slot) {  // halo tile of input frame i, chunk cc -> ring slot
     const int t = tb0 - a.pad_t + i;
+    const bool t_ok = (unsigned)t < (unsigned)a.t_in;
     d.do_x = true;
-    d.t_ok = (unsigned)t < (unsigned)a.t_in;
+    d.xrec = t_ok ? frame_bytes - cc * CK * ES : 0;  // frame outside the clip: all zeros
     d.xb = ring + slot * C::X_BYTES + lds_wave_off;
-    d.xsrc = xclip + ((long long)t * HWp * a.ld_x + cc * CK) * ES;
+    d.xsrc = xclip + ((long long)(t_ok ? t : 0) * HWp * a.ld_x + cc * CK) * ES;
   };
   auto prep_w = [&](Dma& d, int cc, int dt, int tg, int s) {  // weight slice of stage s: [TPS taps][4 chunks][BN]
     d.do_w = true;
     d.wb = wbase + (s & 1) * C::W_BYTES + lds_wave_off;
     d.wsrc = a.wp + (((long long)(cc * a.kt + dt) * TAPS + tg * TPS) * 4 * a.c_out + n0) * 16;
+    d.wrec = (TPS * 4 * a.c_out - n0) * 16;
   };
   auto piece = [&](const Dma& d, int p) {
     if (p < NX) {
-      if (d.do_x && xo[p] > -2) {
-        const char* src = (d.t_ok && xo[p] >= 0) ? d.xsrc + xo[p] : a.zeros;
-        glds16(src, d.xb + p * (C::NTHREADS * 16));
+      if (d.do_x && p * NWV + wv < XWP) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)d.xsrc, 0, d.xrec, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (SFVOS_LDS void*)(d.xb + p * (C::NTHREADS * 16)), 16, xo[p], 0, 0, 0);
       }
     } else {
       const int q = p - NX;
-      if (d.do_w && wo[q] > -2) glds16(d.wsrc + wo[q], d.wb + q * (C::NTHREADS * 16));
+      if (d.do_w && q * NWV + wv < WWP) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)d.wsrc, 0, d.wrec, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (SFVOS_LDS void*)(d.wb + q * (C::NTHREADS * 16)), 16, wo[q], 0, 0, 0);
+      }
     }
   };
   auto issue_all = [&](const Dma& d) {
@@ -205,8 +219,7 @@ __global__ __launch_bounds__(64 * WS * WN, (WS * WN) / 4) void conv3d_kernel(Con
     const char* wbl = wbase + (s & 1) * C::W_BYTES + (hh * C::BN + wn * NT * 32 + r) * 16;
     const char* xfl[TT];
 #pragma unroll
-    for (int j = 0; j < TT; ++j)
-      xfl[j] = ring + wrap(fslot + j) * C::X_BYTES + ((hh * C::HR + ws * MT) * C::HC + r) * 16;
+    for (int j = 0; j < TT; ++j) xfl[j] = ring + wrap(fslot + j) * C::X_BYTES + ws * MT * C::HC * 64;
     // k-step k = (tap_local, st): a PD-deep register pipeline -- the fragments of step k+PD-1 are read
     // from LDS while the MFMAs of step k run, so the wait in front of a step never covers reads that
     // were issued just before it (counted lgkmcnt, not lgkmcnt(0)).
@@ -221,8 +234,9 @@ __global__ __launch_bounds__(64 * WS * WN, (WS * WN) / 4) void conv3d_kernel(Con
       constexpr bool skip_a = false, skip_b = false;
 #endif
       const int tp = k >> 1, st = k & 1;
-      const int tap = tg * TPS + tp;
-      const int dh = (TAPS == 9) ? tap / 3 : 0, dw = (TAPS == 9) ? tap - 3 * dh : 0;
+      // 3x3: a tap group is one kernel row (TPS == 3): dh = tg (runtime), dw = tp (compile-time, indexes xsw)
+      static_assert(TAPS == 1 || TPS == 3, "3x3 layers stage one kernel row per tap group");
+      const int dh = (TAPS == 9) ? tg : 0, dw = (TAPS == 9) ? tp : 0;
 #pragma unroll
       for (int q = 0; q < NT; ++q)
         if (!skip_b) bv[buf][q] = lds_read16(wbl + ((tp * 4 + 2 * st) * C::BN + q * 32) * 16);
@@ -231,7 +245,7 @@ __global__ __launch_bounds__(64 * WS * WN, (WS * WN) / 4) void conv3d_kernel(Con
 #pragma unroll
         for (int i = 0; i < MT; ++i)
           if (!skip_a)
-            av[buf][j][i] = lds_read16(xfl[j] + ((2 * st * C::HR + i + dh) * C::HC + dw) * 16);
+            av[buf][j][i] = lds_read16(xfl[j] + xsw[st][dw] + (i + dh) * C::HC * 64);
     };
 #pragma unroll
     for (int k = 0; k < PD - 1 && k < KS; ++k) load(k, k % PD);
@@ -389,6 +403,11 @@ __global__ __launch_bounds__(64 * WS * WN, (WS * WN) / 4) void conv3d_kernel(Con
       a.stat_part[(prow * 2 + 1) * a.c_out + n0 + tid] = t2;
     }
   }
+}
+
+template <int DT, int TAPS, int TPS, int TT, int MT, int NT, int WS, int WN, int CIN = 0>
+__global__ __launch_bounds__(64 * WS * WN, (WS * WN) / 4) void conv3d_kernel(ConvArgs a) {
+  conv3d_body<DT, TAPS, TPS, TT, MT, NT, WS, WN, CIN>(a);
 }
 
 // ---- frame-split kernel for kt x 3 x 3 convs with c_out <= 32 ----------------------------------------
