@@ -158,7 +158,8 @@ def main():
                                   '%d->%d frames, 5-level pyramid, one launch)' % (l.kt, l.t_in, l.t_out),
                         'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                         'launch_ms': round(dom[1], 4), 'flops_per_launch': dom_flops,
-                        'traffic': pmc_traffic(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json'))}
+                        'traffic': pmc_traffic(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json'))
+                        if (args.sp, args.fp, args.precision) == (4, 32, 'bf16') else None}
         # HBM-bound passes: algorithmic bytes (each tensor touched once per pass) / HIP-event time
         es = 2 if args.precision == 'bf16' else 4
         hbm = {}
