@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
     """Mirror of sfvos_conv_desc (include/sfvos.h)."""
     _fields_ = [('dtype', i32), ('batch', i32), ('t_in', i32), ('t_alloc', i32), ('t_offset', i32), ('c_in', i32),
                 ('c_out', i32), ('kt', i32), ('taps', i32), ('pad_t', i32), ('ld_x', i32), ('ld_y', i32),
-                ('accumulate', i32), ('pyr', Pyramid)]
+                ('accumulate', i32), ('pyr', Pyramid), ('x_group_stride', i64)]
 
 
 def make_pyramid(shapes):
@@ -58,6 +58,7 @@ SIGNATURES = {
     'sfvos_last_error': (C.c_char_p, []),
     'sfvos_check_device': (i32, []),
     'sfvos_frames_to_ndhwc': (i32, [vp, i64, i64, i64, i64, vp, i32, i32, i32, i32, i32, i32, vp]),
+    'sfvos_frames_to_groups': (i32, [vp, i64, i64, i64, i64, vp, i32, i32, i32, i32, i32, i64, vp]),
     'sfvos_ndhwc_to_planar': (i32, [vp, i32, vp, i64, i32, i32, vp]),
     'sfvos_planar_to_ndhwc': (i32, [vp, vp, i32, i64, i32, i32, vp]),
     'sfvos_ndhwc_to_frames': (i32, [vp, i32, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, vp]),

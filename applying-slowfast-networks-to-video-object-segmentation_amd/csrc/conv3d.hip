@@ -55,6 +55,10 @@ struct ConvArgs {
   float* stat_part;
   const char* zeros;
   int batch, t_in, t_alloc, t_offset, t_out, c_in, c_out, kt, pad_t, ld_x, ld_y, accumulate;
+  // x addressing: element (position, chunk cc of 64 bytes) at x + cc*x_chunk_bytes + position*x_pitch_bytes:
+  // pyramid NDHWC = (64, ld_x*ES); channel-group-major input = (group stride in bytes, 64)
+  long long x_chunk_bytes;
+  int x_pitch_bytes;
   int t_blocks, n_blocks;  // frame blocks of THIS launch
   int t_first, t_end;      // output frames [t_first, t_end) of this launch (a layer may take two launches:
   int tb_offset, t_blocks_total;  // blocks of TT and of TT-1 frames so that no frame slot is padding)
@@ -93,7 +97,7 @@ template <int DT, int TAPS, int TPS, int TT, int MT, int NT, int WS, int WN, int
 __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
   typedef ConvCfg<DT, TAPS, TPS, TT, MT, NT, WS, WN> C;
   typedef typename Elt<DT>::type T;
-  constexpr int CE = Elt<DT>::CE, CK = 4 * CE, ES = 16 / CE;
+  constexpr int CE = Elt<DT>::CE, CK = 4 * CE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ring = smem;
   char* const wbase = smem + C::R * C::X_BYTES;
@@ -128,7 +132,7 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
   const int ncc = (CIN ? CIN : a.c_in) / CK;
   const long long HWp = (long long)H * W;
   // frame 0 of this clip inside the x buffer (t_alloc frames per clip, the conv's window starts at t_offset)
-  const char* xclip = a.x + (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset) * HWp) * a.ld_x * ES;
+  const char* xclip = a.x + (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset) * HWp) * a.x_pitch_bytes;
 
   f32x16 acc[TT][MT][NT];
 #pragma unroll
@@ -156,7 +160,7 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
     const int j = cq ^ ((col >> 2) & 3);
     const int h = h0 + row - C::HALO, w = w0 + col - C::HALO;
     const bool ok = sl < C::X_SLOTS && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
-    xo[it] = ok ? (unsigned)((((long long)h * W + w) * a.ld_x + j * CE) * ES) : OOB;
+    xo[it] = ok ? (unsigned)(((long long)h * W + w) * a.x_pitch_bytes + j * 16) : OOB;
   }
   int xsw[2][C::HALO ? 3 : 1];  // lane part of an A-fragment address: k-step st, column shift dw
 #pragma unroll
@@ -171,7 +175,7 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
     wo[it] = (sl < C::W_SLOTS && n0 + n < a.c_out) ? (unsigned)((tj * a.c_out + n) * 16) : OOB;
   }
   const int lds_wave_off = wv * 1024;
-  const int frame_bytes = (int)(HWp * a.ld_x * ES);
+  const int frame_bytes = (int)(HWp * a.x_pitch_bytes);
 
   struct Dma {
     const char* xsrc; char* xb; int xrec; bool do_x;
@@ -183,9 +187,9 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
     const int t = tb0 - a.pad_t + i;
     const bool t_ok = (unsigned)t < (unsigned)a.t_in;
     d.do_x = true;
-    d.xrec = t_ok ? frame_bytes - cc * CK * ES : 0;  // frame outside the clip: all zeros
+    d.xrec = t_ok ? frame_bytes - (a.x_pitch_bytes > 64 ? cc * 64 : 0) : 0;  // frame outside the clip: all zeros
     d.xb = ring + slot * C::X_BYTES + lds_wave_off;
-    d.xsrc = xclip + ((long long)(t_ok ? t : 0) * HWp * a.ld_x + cc * CK) * ES;
+    d.xsrc = xclip + (long long)(t_ok ? t : 0) * HWp * a.x_pitch_bytes + cc * a.x_chunk_bytes;
   };
   auto prep_w = [&](Dma& d, int cc, int dt, int tg, int s) {  // weight slice of stage s: [TPS taps][4 chunks][BN]
     d.do_w = true;
@@ -444,7 +448,7 @@ template <int DT, int TT, int RS, int CIN, bool M16>
 __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const ConvArgs::Part& pt) {
   typedef FsCfg<DT, TT, RS> C;
   typedef typename Elt<DT>::type T;
-  constexpr int CE = Elt<DT>::CE, CK = 4 * CE, ES = 16 / CE, MT = C::MT, HM = C::HM;
+  constexpr int CE = Elt<DT>::CE, CK = 4 * CE, MT = C::MT, HM = C::HM;
   static_assert(!M16 || DT == SFVOS_BF16, "16x16x32 is the bf16 path");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ring = smem;
@@ -475,7 +479,7 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
   const int NF = TT + a.kt - 1;
   const int ncc = (CIN ? CIN : a.c_in) / CK;
   const long long HWp = (long long)H * W;
-  const char* xclip = a.x + (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset) * HWp) * a.ld_x * ES;
+  const char* xclip = a.x + (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset) * HWp) * a.x_pitch_bytes;
 
   f32x16 acc[M16 ? 1 : MT];   // 32x32 tiles: [row]
   f32x4 acc16[M16 ? MT : 1][2];  // 16x16 tiles: [row][channel half]
@@ -509,7 +513,7 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
     const int j = cq ^ (M16 ? 2 * ((col >> 2) & 1) : ((col >> 2) & 3));
     const int h = h0 + row - 1, w = w0 + col - 1;
     const bool ok = sl < C::X_SLOTS && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
-    xo[it] = ok ? (unsigned)((((long long)h * W + w) * a.ld_x + j * CE) * ES) : OOB;
+    xo[it] = ok ? (unsigned)(((long long)h * W + w) * a.x_pitch_bytes + j * 16) : OOB;
   }
   int xsw[3];  // lane part of an A-fragment address for column shift dw (chunk 2kh+hh of pixel column r+dw)
 #pragma unroll
@@ -524,7 +528,7 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
     wo[it] = (sl < C::W_SLOTS && n < a.c_out) ? (unsigned)((tj * a.c_out + n) * 16) : OOB;
   }
   const int lds_wave_off = wv * 1024;
-  const int frame_bytes = (int)(HWp * a.ld_x * ES), wslice_bytes = 9 * 4 * a.c_out * 16;
+  const int frame_bytes = (int)(HWp * a.x_pitch_bytes), wslice_bytes = 9 * 4 * a.c_out * 16;
 
   struct Dma {
     const char* xsrc; char* xb; int xrec; bool do_x;
@@ -535,9 +539,10 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
   auto prep_frame = [&](Dma& d, int cc, int i, int slot) {
     const int t = tb0 - a.pad_t + i;
     d.do_x = true;
-    d.xrec = (unsigned)t < (unsigned)a.t_in ? frame_bytes - cc * CK * ES : 0;  // frame outside the clip: all zeros
+    // frame outside the clip: empty descriptor, all zeros.  (pyramid NDHWC: the chunk offset sits inside the pixel)
+    d.xrec = (unsigned)t < (unsigned)a.t_in ? frame_bytes - (a.x_pitch_bytes > 64 ? cc * 64 : 0) : 0;
     d.xb = ring + slot * C::X_BYTES + lds_wave_off;
-    d.xsrc = xclip + ((long long)((unsigned)t < (unsigned)a.t_in ? t : 0) * HWp * a.ld_x + cc * CK) * ES;
+    d.xsrc = xclip + (long long)((unsigned)t < (unsigned)a.t_in ? t : 0) * HWp * a.x_pitch_bytes + cc * a.x_chunk_bytes;
   };
   auto prep_w = [&](Dma& d, int cc, int dt, int s) {  // weight slice of stage s: [9 taps][4 chunks][32]
     d.do_w = true;
@@ -972,9 +977,15 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
   SFVOS_REQUIRE(d->t_offset >= 0 && d->t_alloc >= d->t_offset + d->t_in,
                 "conv: x window [t_offset %d, +t_in %d) exceeds t_alloc %d", d->t_offset, d->t_in, d->t_alloc);
   SFVOS_REQUIRE(d->pad_t >= 0 && d->pad_t < d->kt + 1, "conv: bad pad_t %d", d->pad_t);
-  SFVOS_REQUIRE(d->ld_x >= d->c_in && d->ld_y >= d->c_out, "conv: pitch smaller than channel count");
   const int ce = d->dtype == SFVOS_BF16 ? 8 : 4;
-  SFVOS_REQUIRE(d->ld_x % ce == 0, "conv: ld_x %d must be a multiple of %d (16-byte chunks)", d->ld_x, ce);
+  SFVOS_REQUIRE(d->ld_y >= d->c_out, "conv: pitch smaller than channel count");
+  if (d->x_group_stride != 0) {
+    SFVOS_REQUIRE(d->dtype == SFVOS_BF16 && d->x_group_stride > 0 && d->x_group_stride % 8 == 0,
+                  "conv: the channel-group-major x layout is bf16 only, stride a positive multiple of 8 elements");
+  } else {
+    SFVOS_REQUIRE(d->ld_x >= d->c_in, "conv: pitch smaller than channel count");
+    SFVOS_REQUIRE(d->ld_x % ce == 0, "conv: ld_x %d must be a multiple of %d (16-byte chunks)", d->ld_x, ce);
+  }
   SFVOS_REQUIRE(d->pyr.n_levels >= 1 && d->pyr.n_levels <= SFVOS_MAX_LEVELS, "conv: n_levels %d out of [1,%d]",
                 d->pyr.n_levels, SFVOS_MAX_LEVELS);
   p->t_out = d->t_in + 2 * d->pad_t - d->kt + 1;
@@ -1004,7 +1015,7 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
     const bool live = l < lv.n;
     const int H = live ? d->pyr.h[l] : 1, W = live ? d->pyr.w[l] : 1;
     SFVOS_REQUIRE(H >= 1 && W >= 1, "conv: level %d has bad extent %dx%d", l, H, W);
-    SFVOS_REQUIRE((long long)H * W * d->ld_x * (16 / ce) < (1ll << 31),
+    SFVOS_REQUIRE((long long)H * W * (d->x_group_stride ? 32 : d->ld_x) * (16 / ce) < (1ll << 31),
                   "conv: level %d frame of %dx%d x pitch %d exceeds the 2 GiB per-frame offset range", l, H, W,
                   d->ld_x);
     lv.H[l] = H; lv.W[l] = W;
@@ -1102,7 +1113,7 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
   SFVOS_REQUIRE(!(stat_part && d->accumulate), "conv: statistics are those of the conv result; not available with accumulate");
   SFVOS_REQUIRE(d->ld_y % (d->dtype == SFVOS_BF16 ? 8 : 4) == 0, "conv: ld_y %d must be a multiple of a 16-byte chunk", d->ld_y);
   SFVOS_REQUIRE(!(d->taps == 1 && p.family == 2), "conv: 1x1 conv with c_out > 64 has no kernel instance");
-  if (!bias && !stat_part && d->taps == 1 && !getenv("SFVOS_NO_LATERAL_KERNEL")) {
+  if (!bias && !stat_part && d->taps == 1 && d->x_group_stride == 0 && !getenv("SFVOS_NO_LATERAL_KERNEL")) {
     rc = lateral_dgrad_try(d, x, w_packed, y, (hipStream_t)stream);  // lateral data gradient: its own HBM-bound kernel
     if (rc >= 0) return rc;
   }
@@ -1112,6 +1123,8 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
   a.batch = d->batch; a.t_in = d->t_in; a.t_alloc = d->t_alloc; a.t_offset = d->t_offset; a.t_out = p.t_out;
   a.c_in = d->c_in; a.c_out = d->c_out; a.kt = d->kt;
   a.pad_t = d->pad_t; a.ld_x = d->ld_x; a.ld_y = d->ld_y; a.accumulate = d->accumulate;
+  a.x_pitch_bytes = d->x_group_stride ? 64 : d->ld_x * (16 / (d->dtype == SFVOS_BF16 ? 8 : 4));
+  a.x_chunk_bytes = d->x_group_stride ? d->x_group_stride * 2 : 64;
   a.n_blocks = p.n_blocks; a.t_blocks_total = p.t_blocks;
   { const char* dbg = getenv("SFVOS_CONV_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
 #ifdef SFVOS_STAMP

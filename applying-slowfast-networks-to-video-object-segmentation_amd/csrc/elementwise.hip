@@ -13,8 +13,11 @@ struct PlanarView {
   int T, C, H, W;
 };
 
+// destination element (position, c) at (c / gdiv) * gstride + position * ld + c % gdiv: plain NDHWC is gdiv = C_max
+// (one group), the channel-group-major input layout is gdiv = ld = 32, gstride = positions * 32
 template <int DT>
-__global__ __launch_bounds__(256) void to_ndhwc_kernel(const float* __restrict__ src, PlanarView v, char* dst, int ld) {
+__global__ __launch_bounds__(256) void to_ndhwc_kernel(const float* __restrict__ src, PlanarView v, char* dst, int ld,
+                                                       int gdiv, long long gstride) {
   constexpr int CE = Elt<DT>::CE;
   __shared__ float tile[64][65];
   const int tid = threadIdx.x;
@@ -41,7 +44,8 @@ __global__ __launch_bounds__(256) void to_ndhwc_kernel(const float* __restrict__
       float f[CE];
 #pragma unroll
       for (int e = 0; e < CE; ++e) f[e] = tile[ch * CE + e][px];
-      *(u32x4*)(dst + (((long long)t * HW + p) * ld + c0 + ch * CE) * (16 / CE)) = pack<DT>(f);
+      const int c = c0 + ch * CE;
+      *(u32x4*)(dst + ((c / gdiv) * gstride + ((long long)t * HW + p) * ld + c % gdiv) * (16 / CE)) = pack<DT>(f);
     }
   }
 }
@@ -144,9 +148,24 @@ extern "C" int sfvos_frames_to_ndhwc(const float* src, int64_t st, int64_t sc, i
   PlanarView v{st, sc, sh, sw, T, C, H, W};
   dim3 grid((unsigned)ceil_div64((int64_t)H * W, 64), (unsigned)ceil_div(C, 64), (unsigned)T);
   hipStream_t s = (hipStream_t)stream;
-  DT_DISPATCH(dtype, hipLaunchKernelGGL(to_ndhwc_kernel<SFVOS_F32>, grid, dim3(256), 0, s, src, v, (char*)dst, ld),
-              hipLaunchKernelGGL(to_ndhwc_kernel<SFVOS_BF16>, grid, dim3(256), 0, s, src, v, (char*)dst, ld));
+  DT_DISPATCH(dtype,
+              hipLaunchKernelGGL(to_ndhwc_kernel<SFVOS_F32>, grid, dim3(256), 0, s, src, v, (char*)dst, ld, 1 << 30, 0ll),
+              hipLaunchKernelGGL(to_ndhwc_kernel<SFVOS_BF16>, grid, dim3(256), 0, s, src, v, (char*)dst, ld, 1 << 30, 0ll));
   return check_launch("frames_to_ndhwc");
+}
+
+extern "C" int sfvos_frames_to_groups(const float* src, int64_t st, int64_t sc, int64_t sh, int64_t sw, void* dst,
+                                      int dtype, int T, int C, int H, int W, int64_t group_stride,
+                                      sfvos_stream_t stream) {
+  SFVOS_REQUIRE(src && dst && T > 0 && C > 0 && H > 0 && W > 0, "frames_to_groups: bad argument");
+  SFVOS_REQUIRE(dtype == SFVOS_BF16, "frames_to_groups: the channel-group-major layout is bf16 only");
+  SFVOS_REQUIRE(C % 32 == 0 && group_stride >= (int64_t)T * H * W * 32 && group_stride % 8 == 0,
+                "frames_to_groups: C must be a multiple of 32 and group_stride >= T*H*W*32");
+  PlanarView v{st, sc, sh, sw, T, C, H, W};
+  dim3 grid((unsigned)ceil_div64((int64_t)H * W, 64), (unsigned)ceil_div(C, 64), (unsigned)T);
+  hipLaunchKernelGGL(to_ndhwc_kernel<SFVOS_BF16>, grid, dim3(256), 0, (hipStream_t)stream, src, v, (char*)dst, 32, 32,
+                     (long long)group_stride);
+  return check_launch("frames_to_groups");
 }
 
 extern "C" int sfvos_planar_to_ndhwc(const float* src, void* dst, int dtype, int64_t M, int C, int ld,

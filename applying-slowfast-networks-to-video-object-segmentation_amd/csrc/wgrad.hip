@@ -40,6 +40,7 @@ struct WgradArgs {
   float* slab;
   const char* zeros;
   int t_in, t_alloc, t_offset, t_out, c_in, c_out, kt, ld_x, ld_y, batch;
+  long long x_group_bytes;  // 0: x is pyramid NDHWC (pitch ld_x); else bytes between its 64-byte channel groups (bf16)
   int n_blocks, c_blocks, dt_blocks, psplit;
   int ntiles;  // over all levels and clips
   WgradLevels lv;
@@ -54,8 +55,9 @@ struct WgradCfg {
   static constexpr int HR = TH + 2 * HALO, HC = 16 + 2 * HALO;
   static constexpr int NPOS = TH * 16, NHPOS = HR * HC;
   static constexpr int DY_SLOTS = NTN * NPOS * SPP;   // one dy frame
-  static constexpr int X_SLOTS = NTC * NHPOS * SPP;   // one x halo tile
-  static constexpr int DWP = (DY_SLOTS + 63) / 64, XWP = (X_SLOTS + 63) / 64;  // 64-slot wave-pieces
+  static constexpr int XT_SLOTS = ((NHPOS * SPP + 63) / 64) * 64;  // one 32-channel x halo tile, padded to whole
+  static constexpr int X_SLOTS = NTC * XT_SLOTS;                   // 64-slot wave-pieces (a piece = one channel group)
+  static constexpr int DWP = (DY_SLOTS + 63) / 64, XWP = X_SLOTS / 64;
   static constexpr int DY_BYTES = DWP * 1024, X_BYTES = XWP * 1024;
   static constexpr int LDS_BYTES = R * X_BYTES + 2 * DY_BYTES;
   static_assert(NTN * NTC * DG == 8, "one (n-tile, c-tile, dt) group per wave");
@@ -139,15 +141,19 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     tile_geom(tile, lvl, b, h0, w0);
     const int H = a.lv.H[lvl], W = a.lv.W[lvl];
     const long long HWp = (long long)H * W;
-    x_fstride = HWp * a.ld_x * ES;
-    x_frame0 = a.x + (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset + dt0) * HWp) * a.ld_x * ES;
+    const int pitch = a.x_group_bytes ? 64 : a.ld_x * ES;  // bytes per position
+    x_fstride = HWp * pitch;
+    x_frame0 = a.x + (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset + dt0) * HWp) * pitch;
 #pragma unroll
     for (int it = 0; it < NXP; ++it) {
       const int sl = it * 512 + tid;
-      const int j = sl % C::SPP, hp = (sl / C::SPP) % C::NHPOS, tct = sl / (C::SPP * C::NHPOS);
+      const int tct = sl / C::XT_SLOTS, ts = sl - tct * C::XT_SLOTS;
+      const int j = ts % C::SPP, hp = ts / C::SPP;
       const int h = h0 + hp / C::HC - C::HALO, w = w0 + hp % C::HC - C::HALO, c = c_base + tct * 32;
-      const bool ok = sl < C::X_SLOTS && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W && c < a.c_in;
-      xo[it] = ok ? (unsigned)((((long long)h * W + w) * a.ld_x + c + j * CE) * ES) : OOB;
+      const bool ok = sl < C::X_SLOTS && hp < C::NHPOS && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W &&
+                      c < a.c_in;
+      // the channel-group term of the grouped layout goes into the piece's base pointer (x_piece), not the offset
+      xo[it] = ok ? (unsigned)(((long long)h * W + w) * pitch + (a.x_group_bytes ? 0 : c * ES) + j * 16) : OOB;
     }
   };
   auto enter_tile_dy = [&](int tile) {
@@ -183,7 +189,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   };
   auto x_piece = [&](const Copy& c, int p) {
     if (p * 8 + wv < C::XWP) {
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)c.src, 0, c.rec, 0x00020000);
+      // wave-piece -> its 32-channel tile -> (grouped layout) that tile's channel group
+      const long long goff = a.x_group_bytes * ((c_base >> 5) + (p * 8 + wv) / (C::XT_SLOTS / 64));
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(c.src + goff), 0, c.rec, 0x00020000);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (SFVOS_LDS void*)(c.dst + p * 8192), 16, xo[p], 0, 0, 0);
     }
   };
@@ -207,7 +215,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   static_assert(2 * NXP + NDY + 2 <= NSTEP || DT != SFVOS_BF16, "the copies of a stage must fit between its MFMA steps");
   auto compute = [&](int s, int q0, int nx, bool ndy) {
     const char* dyb = dybase + (s & 1) * C::DY_BYTES + nt * (C::NPOS * C::ROWB);
-    const char* xb = xbase + ((q0 + dg) % R) * C::X_BYTES + ct * (C::NHPOS * C::ROWB);
+    const char* xb = xbase + ((q0 + dg) % R) * C::X_BYTES + ct * (C::XT_SLOTS * 16);
     Copy cx, cd;
     // copy schedule by step: [0] begin x#1, [0..NXP) its pieces, [NXP] begin x#2, then its pieces, then dy
     auto copies = [&](int step) {
@@ -412,7 +420,12 @@ static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
   SFVOS_REQUIRE(d->c_in % 32 == 0 && d->c_out % 32 == 0 && d->c_in > 0 && d->c_out > 0, "wgrad: channels % 32");
   SFVOS_REQUIRE(d->pad_t == 0, "wgrad: only forward convs (pad_t == 0) have a weight gradient here");
   const int ce = d->dtype == SFVOS_BF16 ? 8 : 4;
-  SFVOS_REQUIRE(d->ld_x % ce == 0 && d->ld_y % ce == 0 && d->ld_x >= d->c_in && d->ld_y >= d->c_out, "wgrad: pitch");
+  SFVOS_REQUIRE(d->ld_y % ce == 0 && d->ld_y >= d->c_out, "wgrad: pitch");
+  if (d->x_group_stride != 0)
+    SFVOS_REQUIRE(d->dtype == SFVOS_BF16 && d->x_group_stride > 0 && d->x_group_stride % 8 == 0,
+                  "wgrad: the channel-group-major x layout is bf16 only, stride a positive multiple of 8 elements");
+  else
+    SFVOS_REQUIRE(d->ld_x % ce == 0 && d->ld_x >= d->c_in, "wgrad: pitch");
   p->t_out = d->t_in - d->kt + 1;
   SFVOS_REQUIRE(p->t_out >= 1, "wgrad: kt > t_in");
   const bool f32 = d->dtype == SFVOS_F32;
@@ -513,6 +526,7 @@ extern "C" int sfvos_conv3d_wgrad(const sfvos_conv_desc* d, const void* x, const
   a.t_in = d->t_in; a.t_alloc = d->t_alloc; a.t_offset = d->t_offset; a.t_out = p.t_out; a.c_in = d->c_in;
   a.c_out = d->c_out; a.kt = d->kt;
   a.ld_x = d->ld_x; a.ld_y = d->ld_y; a.batch = d->batch;
+  a.x_group_bytes = d->x_group_stride * 2;
   a.n_blocks = p.n_blocks; a.c_blocks = p.c_blocks;
   a.dt_blocks = p.dt_blocks; a.psplit = p.psplit;
   a.ntiles = p.ntiles; a.lv = p.lv;

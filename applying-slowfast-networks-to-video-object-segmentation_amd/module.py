@@ -87,24 +87,44 @@ class PackedClip(object):
     """Channels-last clips of a whole pyramid in the layout the kernels consume (a
     producer that emits NHWC frames hands them over without any layout pass).
 
-    data : [B * frames * sum_l(H_l*W_l), C] tensor in the compute dtype, level-major
-           (position(l,b,t,h,w) as in include/sfvos.h)
+    data : [M, C] tensor in the compute dtype, M = B * frames * sum_l(H_l*W_l) positions, level-major
+           (position(l,b,t,h,w) as in include/sfvos.h) -- layout 'ndhwc'; or
+           [C/32, M, 32] (bf16 only) -- layout 'grouped': the channels of a position are stored as 64-byte groups,
+           group-major (sfvos_conv_desc.x_group_stride).  The first convs stream the input one 64-byte channel
+           chunk at a time; in this layout every 128-byte line they touch is used whole (fewer L2 misses).
     """
 
     def __init__(self, data, shapes, batch, frames, keys=None):
         self.data, self.shapes, self.batch, self.frames = data, [tuple(s) for s in shapes], batch, frames
         self.keys = list(keys) if keys is not None else [str(i) for i in range(len(shapes))]
-        pix = sum(h * w for h, w in self.shapes)
-        if data.dim() != 2 or data.shape[0] != batch * frames * pix:
-            raise ValueError('PackedClip: data must be [B*frames*sum(H*W), C] = [%d, C], got %s'
-                             % (batch * frames * pix, tuple(data.shape)))
+        M = batch * frames * sum(h * w for h, w in self.shapes)
+        ok = (data.dim() == 2 and data.shape[0] == M) or (data.dim() == 3 and data.shape[1] == M and data.shape[2] == 32)
+        if not ok:
+            raise ValueError('PackedClip: data must be [%d, C] (ndhwc) or [C/32, %d, 32] (grouped), got %s'
+                             % (M, M, tuple(data.shape)))
+
+    @property
+    def layout(self):
+        return 'grouped' if self.data.dim() == 3 else 'ndhwc'
+
+    @property
+    def channels(self):
+        return self.data.shape[0] * 32 if self.data.dim() == 3 else self.data.shape[1]
 
     @staticmethod
-    def from_levels(levels, keys=None):
+    def from_levels(levels, keys=None, layout='ndhwc'):
         """levels: list of [B,T,H,W,C] tensors (one per FPN level) -> PackedClip (copies once)."""
         B, T = levels[0].shape[0], levels[0].shape[1]
         shapes = [tuple(x.shape[2:4]) for x in levels]
-        data = torch.cat([x.reshape(-1, x.shape[-1]) for x in levels], 0)
+        if layout == 'grouped':
+            C = levels[0].shape[-1]
+            if C % 32 != 0 or levels[0].dtype != torch.bfloat16:
+                raise ValueError("PackedClip layout 'grouped' needs bf16 data with C a multiple of 32")
+            data = torch.cat([x.reshape(-1, C // 32, 32).permute(1, 0, 2) for x in levels], 1).contiguous()
+        elif layout == 'ndhwc':
+            data = torch.cat([x.reshape(-1, x.shape[-1]) for x in levels], 0)
+        else:
+            raise ValueError("PackedClip layout must be 'ndhwc' or 'grouped'")
         return PackedClip(data, shapes, B, T, keys)
 
 
@@ -189,7 +209,14 @@ class SlowFastLayers(nn.Module):
         return packed
 
     def _desc(self, layer, B, pyr, dt_id, ld_x, ld_y, t_alloc=None, t_offset=0, dgrad=False, accumulate=0):
+        """ld_x: pitch of x in elements, or the x tensor itself ([M, ld] ndhwc / [G, M, 32] grouped)."""
         d = _lib.ConvDesc()
+        d.x_group_stride = 0
+        if torch.is_tensor(ld_x):
+            if ld_x.dim() == 3:
+                d.x_group_stride, ld_x = ld_x.shape[1] * 32, 32
+            else:
+                ld_x = ld_x.shape[-1]
         d.dtype, d.batch, d.kt, d.taps, d.pyr = dt_id, B, layer.kt, layer.taps, pyr
         if dgrad:  # conv over dy producing dx: channels swapped, full temporal padding
             d.t_in, d.c_in, d.c_out, d.pad_t = layer.t_out, layer.c_out, layer.c_in, layer.kt - 1
@@ -255,7 +282,7 @@ class SlowFastLayers(nn.Module):
                     bufs[name] = torch.empty((B * b.frames * pix, b.channels), dtype=tdt, device=dev)
             sname, t_alloc, t_off = self._src_window(l, slow_offset)
             src = bufs[sname]
-            d = self._desc(l, B, pyr, dt_id, src.shape[-1], l.c_out, t_alloc, t_off)
+            d = self._desc(l, B, pyr, dt_id, src, l.c_out, t_alloc, t_off)
             lv = _lib.make_levels(shapes, B, l.t_out)
             w = dict(d=d, lv=lv, src=src, wp=self._packed(l, 'fwd', dt_name),
                      cf=torch.empty((L, _CF_ROWS, l.c_out), dtype=torch.float32, device=dev))
@@ -420,7 +447,7 @@ class SlowFastLayers(nn.Module):
             sname, t_alloc, t_off = self._src_window(l, state.slow_offset)
             w['src'] = bufs[sname]
             if need_w:
-                d = self._desc(l, B, pyr, dt_id, w['src'].shape[-1], l.c_out, t_alloc, t_off)
+                d = self._desc(l, B, pyr, dt_id, w['src'], l.c_out, t_alloc, t_off)
                 nbytes = lib.sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
                 if nbytes == 0:
                     _lib.check(-1, 'sfvos_conv3d_wgrad_workspace_bytes')
@@ -503,15 +530,23 @@ class SlowFastLayers(nn.Module):
         """list over levels of [B,C,T,H,W] fp32 (any strides) -> flat pyramid buffer (model.py:157-158)."""
         B, C = tensors[0].shape[0], tensors[0].shape[1]
         pix = sum(t.shape[3] * t.shape[4] for t in tensors)
-        flat = torch.empty((B * frames * pix, C), dtype=tdt, device=tensors[0].device)
+        M = B * frames * pix
+        # bf16: channel-group-major ([C/32][M][32], see PackedClip) -- the layout the first convs read fastest
+        grouped = tdt == torch.bfloat16 and C % 32 == 0 and os.environ.get('SFVOS_INPUT_LAYOUT', 'grouped') != 'ndhwc'
+        flat = torch.empty((C // 32, M, 32) if grouped else (M, C), dtype=tdt, device=tensors[0].device)
         st = _stream()
         off = 0
         for t in tensors:
             s = t if t.dtype == torch.float32 else t.float()
             H, W = s.shape[3], s.shape[4]
             for b in range(B):
-                _lib.call('sfvos_frames_to_ndhwc', _ptr(s[b]), s.stride(2), s.stride(1), s.stride(3), s.stride(4),
-                          _ptr(flat, (off + b * frames * H * W) * C), dt_id, frames, C, H, W, C, st)
+                pos = off + b * frames * H * W
+                if grouped:
+                    _lib.call('sfvos_frames_to_groups', _ptr(s[b]), s.stride(2), s.stride(1), s.stride(3), s.stride(4),
+                              _ptr(flat, pos * 32), dt_id, frames, C, H, W, M * 32, st)
+                else:
+                    _lib.call('sfvos_frames_to_ndhwc', _ptr(s[b]), s.stride(2), s.stride(1), s.stride(3), s.stride(4),
+                              _ptr(flat, pos * C), dt_id, frames, C, H, W, C, st)
             off += B * frames * H * W
         return flat
 
@@ -577,7 +612,7 @@ class SlowFastLayers(nn.Module):
         self._check_ready(clip.data)
         plan = self.plan
         _, tdt = _DT[self.precision]
-        if clip.frames != plan.fp or clip.data.shape[1] != plan.input_size or clip.data.dtype != tdt \
+        if clip.frames != plan.fp or clip.channels != plan.input_size or clip.data.dtype != tdt \
                 or not clip.data.is_contiguous():
             raise RuntimeError('PackedClip must hold %d frames x %d channels, contiguous %s'
                                % (plan.fp, plan.input_size, tdt))
@@ -660,7 +695,7 @@ class _SlowFastPyramidFn(torch.autograd.Function):
         else:
             g = None
             if need_fast:
-                g = gb['xf0'].clone()
+                g = gb['xf0'].clone()   # data gradients are pyramid NDHWC [M, C]
                 gs = gb['xs0']  # slow window gradient, added into its frames of the fast clip (plumbing adds)
                 sp, fp, so = module.plan.sp, module.plan.fp, state.slow_offset
                 off_f = off_s = 0
@@ -671,6 +706,8 @@ class _SlowFastPyramidFn(torch.autograd.Function):
                     vf[:, so: so + sp] += vs
                     off_f += B * fp * P
                     off_s += B * sp * P
+                if state.bufs['xf0'].dim() == 3:  # the clip came channel-group-major: hand its gradient back that way
+                    g = g.view(g.shape[0], -1, 32).permute(1, 0, 2).contiguous()
             out.append(g)
         for n in names:
             out.append(grads.get(n) if need_param[n] else None)

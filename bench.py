@@ -36,6 +36,7 @@ def parse():
                          'durations, the default here); 2 = slow pathway on a side stream (module default, ~5 %% '
                          'more clips/s, but concurrent kernels stretch each other\'s measured duration)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--ndhwc-input', action='store_true', help='hand the clip over as plain pyramid NDHWC (A/B of the grouped layout)')
     ap.add_argument('--no-grad-sink', action='store_true',
                     help='let autograd accumulate parameter gradients from temporaries (A/B of FusedSGD.attach)')
     ap.add_argument('--cpu-threads', type=int, default=0)
@@ -109,7 +110,9 @@ def main():
     # one clip = the fast window of every FPN level, channels-last, already in the pyramid layout
     levels = [torch.randn((1, args.fp, h, w, 256), generator=gen, device=dev, dtype=torch.float32).to(tdt)
               for _, (h, w) in pyr]
-    clip = PackedClip.from_levels(levels, keys=[k for k, _ in pyr])
+    # bf16: the clip is handed over channel-group-major (64-byte groups), the layout the first convs read fastest
+    clip = PackedClip.from_levels(levels, keys=[k for k, _ in pyr],
+                                  layout='grouped' if (args.precision == 'bf16' and not args.ndhwc_input) else 'ndhwc')
     del levels
 
     timer = model.enable_kernel_timer()

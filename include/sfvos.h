@@ -76,6 +76,12 @@ int sfvos_frames_to_ndhwc(const float* src, int64_t stride_t, int64_t stride_c, 
                           int64_t stride_w, void* dst, int dtype, int T, int C, int H, int W, int ld,
                           sfvos_stream_t stream);
 
+/* Same source -> the channel-group-major layout of sfvos_conv_desc.x_group_stride (bf16 only): element
+ * (t,h,w,c) at dst + (c/32)*group_stride + ((t*H+h)*W+w)*32 + c%32; C a multiple of 32. */
+int sfvos_frames_to_groups(const float* src, int64_t stride_t, int64_t stride_c, int64_t stride_h,
+                           int64_t stride_w, void* dst, int dtype, int T, int C, int H, int W,
+                           int64_t group_stride, sfvos_stream_t stream);
+
 /* NDHWC src[M][ld] (first C channels) -> planar fp32 dst[C][M]. */
 int sfvos_ndhwc_to_planar(const void* src, int dtype, float* dst, int64_t M, int C, int ld,
                           sfvos_stream_t stream);
@@ -122,6 +128,10 @@ typedef struct sfvos_conv_desc {
   int ld_x, ld_y;  /* per-position pitch of x / y in elements */
   int accumulate;  /* y += conv(x) instead of y = conv(x)  (gradient fan-in) */
   sfvos_pyramid pyr; /* spatial extents of the levels (stride 1: output spatial == input spatial) */
+  int64_t x_group_stride; /* 0: x is pyramid NDHWC with pitch ld_x.  > 0 (bf16 only): x is stored as 64-byte
+                           * channel groups, element (position, c) at (c/32)*x_group_stride + position*32 + c%32
+                           * (ld_x ignored): every 128-byte line a kernel touches is used whole, so the
+                           * temporal re-reads of the input hit in L2 instead of fetching half-used lines. */
 } sfvos_conv_desc;
 
 /* Partial-statistics rows ([2][c_out] fp32 each, one per workgroup tile) sfvos_conv3d writes for

@@ -188,6 +188,58 @@ def test_conv3d_dgrad_and_accumulate(lib, prec, case):
         assert relmax(a, 2 * x.grad) < 2 * TOL[prec]
 
 
+@pytest.mark.parametrize('case', [(1, 6, [(12, 21), (5, 9)], 256, 32, 3, 9),    # frame-split kernel
+                                  (2, 4, [(9, 17), (3, 3)], 256, 192, 2, 9),    # wide kernel, two clips
+                                  (1, 5, [(10, 12)], 64, 32, 2, 9)])
+def test_grouped_input_layout_is_bit_identical(lib, case):
+    """x stored as 64-byte channel groups (sfvos_frames_to_groups, sfvos_conv_desc.x_group_stride): the conv
+    (with a frame window, as the slow pathway reads the fast clip) and the weight gradient must give exactly
+    the bits they give for the same values in pyramid NDHWC -- only the addresses differ."""
+    B, T, shapes, cin, cout, kt, taps = case
+    g = torch.Generator().manual_seed(321)
+    w = torch.randn(cout, cin, kt, 3, 3, generator=g) / np.sqrt(cin * kt * taps)
+    xs = [torch.randn(B, cin, T, H, W, generator=g) for (H, W) in shapes]
+    x_nd = to_pyr(xs, 'bf16')
+    M = x_nd.shape[0]
+    # grouped buffer built by the library from the planar frames (one call per level and clip)
+    x_gr = torch.full((cin // 32, M, 32), 5.0, dtype=torch.bfloat16, device='cuda')
+    off = 0
+    for x in xs:
+        H, W = x.shape[3], x.shape[4]
+        xc = x.cuda()
+        for b in range(B):
+            s = xc[b]  # [C,T,H,W]
+            lib.call('sfvos_frames_to_groups', P(s), s.stride(1), s.stride(0), s.stride(2), s.stride(3),
+                     P(x_gr, (off + b * T * H * W) * 32), lib.BF16, T, cin, H, W, M * 32, S())
+        off += B * T * H * W
+    assert torch.equal(x_gr.permute(1, 0, 2).reshape(M, cin), x_nd), 'frames_to_groups != NDHWC values'
+    t_win, t_off = T - 1, 1  # read frames [1, T) of the buffer
+    outs, grads = [], []
+    for x, gs in ((x_nd, 0), (x_gr, M * 32)):
+        d, t_out = make_desc(lib, 'bf16', B, t_win, shapes, cin, cout, kt, taps, 0, cin if gs == 0 else 32, cout,
+                             t_alloc=T, t_offset=t_off)
+        d.x_group_stride = gs
+        wp = torch.empty(w.numel(), dtype=torch.bfloat16, device='cuda')
+        lib.call('sfvos_pack_weights_fwd', P(w.cuda()), P(wp), d.dtype, cout, cin, kt, taps, S())
+        Mo = sum(B * t_out * H * W for H, W in shapes)
+        y = torch.zeros((Mo, cout), dtype=torch.bfloat16, device='cuda')
+        zeros = torch.zeros(1024, dtype=torch.uint8, device='cuda')
+        lib.call('sfvos_conv3d', ctypes.byref(d), P(x), P(wp), None, P(y), None, P(zeros), S())
+        outs.append(y)
+        dy = (torch.randn(Mo, cout, generator=torch.Generator().manual_seed(5)) * 0.1).bfloat16().cuda()
+        ws = torch.empty(lib.load().sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d)), dtype=torch.uint8, device='cuda')
+        gw = torch.empty(w.shape, dtype=torch.float32, device='cuda')
+        lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(x), P(dy), P(gw), 0, P(ws), P(zeros), S())
+        grads.append(gw)
+    torch.cuda.synchronize()
+    assert float(outs[0].float().abs().max()) > 0.1
+    assert torch.equal(outs[0], outs[1]), 'conv differs between the two input layouts'
+    assert torch.equal(grads[0], grads[1]), 'weight gradient differs between the two input layouts'
+    ref = [F.conv3d(x.bfloat16().float()[:, :, t_off:], w.bfloat16().float(), None, padding=(0, 1, 1)) for x in xs]
+    for a, r in zip(from_pyr(outs[1], B, cout, t_win - kt + 1, shapes), ref):
+        assert relmax(a, r) < TOL['bf16']
+
+
 WGRAD_CASES = [
     (1, 4, [(12, 21), (6, 10)], 256, 32, 2, 9),    # cfg (1,2,4): c_out 32, c_in 256
     (1, 3, [(9, 17)], 256, 192, 2, 9),             # cfg (2,2,2)

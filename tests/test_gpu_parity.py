@@ -265,3 +265,41 @@ def test_packed_clip_matches_frame_lists_and_backward():
         assert torch.equal(out[k], out2[k])
     for k, p in m2.named_parameters():
         assert torch.equal(p.grad, ref_g[k]), k
+
+
+def test_grouped_packed_clip_matches_ndhwc_and_returns_grouped_input_gradient():
+    """bf16: a clip handed over channel-group-major (PackedClip layout 'grouped') gives the same bits as the same
+    clip in pyramid NDHWC -- outputs, parameter gradients and the gradient w.r.t. the clip, which comes back in
+    the layout the clip was given in; temporally_enhance_features (which builds the grouped layout itself in bf16)
+    agrees with both."""
+    from sfvos_amd import PackedClip
+    sp, fp = 3, 7
+    _, fast = clip_inputs(sp, fp, SMALL_LEVELS, 0, torch.device('cuda:0'))
+    levels = [fast[0][k].permute(0, 2, 3, 1).unsqueeze(0).contiguous().bfloat16() for k in SMALL_LEVELS]  # [1,T,H,W,C]
+    res = {}
+    for layout in ('ndhwc', 'grouped'):
+        m, dev = build(sp, fp, 'bf16')
+        m.train()
+        clip = PackedClip.from_levels(levels, keys=list(SMALL_LEVELS.keys()), layout=layout)
+        assert clip.layout == layout and clip.channels == 256
+        clip.data.requires_grad_(True)
+        out = m.enhance_packed(clip)
+        proxy_loss(out).backward()
+        gx = clip.data.grad
+        assert gx.shape == clip.data.shape
+        if layout == 'grouped':
+            gx = gx.permute(1, 0, 2).reshape(gx.shape[1], -1)
+        res[layout] = (out, {k: p.grad.clone() for k, p in m.named_parameters()}, gx)
+    for k in res['ndhwc'][0]:
+        assert torch.equal(res['ndhwc'][0][k], res['grouped'][0][k]), k
+    for k in res['ndhwc'][1]:
+        assert torch.equal(res['ndhwc'][1][k], res['grouped'][1][k]), k
+    assert torch.equal(res['ndhwc'][2], res['grouped'][2])
+    m, dev = build(sp, fp, 'bf16')
+    m.train()
+    fast_bf = [OrderedDict((k, v.bfloat16().float()) for k, v in fast[0].items())]
+    from oracle.closed_form import slice_slow
+    slow_bf = [slice_slow(fast_bf[0], sp)]
+    out3 = m.temporally_enhance_features(slow_bf, fast_bf)
+    for k in out3:
+        assert torch.equal(out3[k], res['grouped'][0][k]), k
