@@ -45,14 +45,15 @@ def parse():
 
 def cpu_baseline(sp, fp, threads):
     """The oracle (torch-CPU restatement of the reference path) timed on this box's host cores on a
-    bounded sample: ONE clip's FPN level '1' (96x168 = 18.8 % of the clip's positions), fwd+bwd."""
+    bounded sample: ONE clip's FPN level '0' (192x336 = 75 % of the clip's positions, 10-20 s), fwd+bwd."""
     from oracle.slowfast_ref import OracleSlowFastLayers, proxy_loss
     from sfvos_amd import davis_pyramid
     if threads > 0:
         torch.set_num_threads(threads)
     cores = torch.get_num_threads()
     pyr = dict(davis_pyramid())
-    H, W = pyr['1']
+    level = '0'
+    H, W = pyr[level]
     P = sum(h * w for h, w in pyr.values())
     torch.manual_seed(63)
     m = OracleSlowFastLayers(256, torch.device('cpu'), sp, fp)
@@ -61,13 +62,13 @@ def cpu_baseline(sp, fp, threads):
     slow = fast[:, :, fp // 2 - sp // 2: fp // 2 + (sp + 1) // 2]
     t0 = time.time()
     s, f = m(slow, fast)
-    loss = proxy_loss({'1': torch.cat([s, f], 1).squeeze(2)})
+    loss = proxy_loss({level: torch.cat([s, f], 1).squeeze(2)})
     loss.backward()
     dt = time.time() - t0
     frac = float(H * W) / P
     return {'value': frac / dt, 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
-            'sample': "oracle fwd+bwd of FPN level '1' (96x168, %.1f%% of one clip's positions) in %.1f s, "
-                      "scaled by position share" % (100 * frac, dt)}
+            'sample': "oracle fwd+bwd of FPN level '%s' (%dx%d, %.1f%% of one clip's positions) in %.1f s, "
+                      "scaled by position share" % (level, H, W, 100 * frac, dt)}
 
 
 def pmc_traffic(path):
