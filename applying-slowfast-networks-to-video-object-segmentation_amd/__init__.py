@@ -5,9 +5,9 @@ Public surface mirrors the reference's `helpers/model.py` for this path:
 plus the pieces the reference's train.py builds around it (SGD step, gradient averaging for
 one-process-per-GPU data parallelism)."""
 from .plan import SlowFastPlan, calc_fuse_kernel_size, calc_kernel_sizes, davis_pyramid  # noqa: F401
-from .module import PackedClip, SlowFastLayers  # noqa: F401
+from .module import PackedClip, SlowFastLayers, union_mask  # noqa: F401
 from .optim import FusedSGD  # noqa: F401
 from .parallel import GradBucket, init_distributed  # noqa: F401
 
 __all__ = ['SlowFastLayers', 'PackedClip', 'SlowFastPlan', 'FusedSGD', 'GradBucket', 'init_distributed',
-           'calc_kernel_sizes', 'calc_fuse_kernel_size', 'davis_pyramid']
+           'calc_kernel_sizes', 'calc_fuse_kernel_size', 'davis_pyramid', 'union_mask']

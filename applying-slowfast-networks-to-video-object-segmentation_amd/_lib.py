@@ -80,6 +80,7 @@ SIGNATURES = {
     'sfvos_reduce_rows': (i32, [vp, i32, i32, vp, i32, vp]),
     'sfvos_sgd_step': (i32, [vp, vp, vp, i64, f32, f32, f32, i32, vp]),
     'sfvos_scale': (i32, [vp, i64, f32, vp]),
+    'sfvos_mask_union': (i32, [vp, i32, i64, f32, vp, vp]),
 }
 
 _lib = None

@@ -85,6 +85,16 @@ __global__ __launch_bounds__(256) void from_ndhwc_kernel(const char* __restrict_
   }
 }
 
+// ---- evaluation: union of thresholded masks (davis_evaluate.py:40-42) ------------------------------
+__global__ __launch_bounds__(256) void mask_union_kernel(const float* __restrict__ masks, int n, long long hw, float thr,
+                                                         unsigned char* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long long)gridDim.x * 256) {
+    unsigned char any = 0;
+    for (int k = 0; k < n; ++k) any |= (unsigned char)(masks[(long long)k * hw + i] >= thr);
+    out[i] = any;
+  }
+}
+
 // ---- weight packing -----------------------------------------------------------------------------
 // packed[cc][dt][tap][j][n][e]  (one 16-B chunk = CE reduction channels for one output channel n;
 // a conv stage (cc, dt, tap group) is one contiguous block)
@@ -230,6 +240,14 @@ extern "C" int sfvos_pack_weights_fwd(const float* w, void* packed, int dtype, i
 extern "C" int sfvos_pack_weights_dgrad(const float* w, void* packed, int dtype, int c_out, int c_in, int kt, int taps,
                                         sfvos_stream_t stream) {
   return pack_common(w, packed, dtype, c_out, c_in, kt, taps, true, stream);
+}
+
+extern "C" int sfvos_mask_union(const float* masks, int n, int64_t hw, float threshold, unsigned char* out,
+                                sfvos_stream_t stream) {
+  SFVOS_REQUIRE(out && hw > 0 && n >= 0 && (masks || n == 0), "mask_union: bad argument");
+  hipLaunchKernelGGL(mask_union_kernel, dim3(grid_for(hw, 256)), dim3(256), 0, (hipStream_t)stream, masks, n,
+                     (long long)hw, threshold, out);
+  return check_launch("mask_union");
 }
 
 extern "C" int sfvos_reduce_rows(const float* part, int rows, int C, float* out, int accumulate,

@@ -83,6 +83,21 @@ class _NullRegion(object):
 _NULL = _NullRegion()
 
 
+def union_mask(masks, threshold=0.5):
+    """Evaluation-side reducer of the reference (code/helpers/davis_evaluate.py:40-42): the union over the
+    predicted instance masks [N,1,H,W] (fp32 probabilities, on the GPU) of `mask >= threshold` -> bool [H,W]."""
+    if not masks.is_cuda:
+        raise RuntimeError('union_mask runs on the GPU through libsfvos.so (no CPU fallback)')
+    if masks.dim() != 4 or masks.shape[1] != 1:
+        raise RuntimeError('union_mask expects [N,1,H,W], got %s' % (tuple(masks.shape),))
+    m = masks if (masks.dtype == torch.float32 and masks.is_contiguous()) else masks.float().contiguous()
+    H, W = m.shape[2], m.shape[3]
+    out = torch.empty((H, W), dtype=torch.uint8, device=m.device)
+    _lib.call('sfvos_mask_union', _ptr(m) if m.shape[0] else None, m.shape[0], H * W, float(threshold), _ptr(out),
+              _stream())
+    return out.bool()
+
+
 class PackedClip(object):
     """Channels-last clips of a whole pyramid in the layout the kernels consume (a
     producer that emits NHWC frames hands them over without any layout pass).

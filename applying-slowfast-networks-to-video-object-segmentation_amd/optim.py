@@ -67,6 +67,54 @@ class FusedSGD(torch.optim.Optimizer):
     def end_direct(self):
         self._clean = False
 
+    # -- checkpoint interchange with torch.optim.SGD (reference train.py:117-121 saves opt.state_dict(),
+    # train.py:57-60 / train_osvos.py restore it): same dictionary layout in both directions
+    def state_dict(self):
+        """torch.optim.SGD's state-dict layout: one param group with torch's own hyper-parameter keys and, once a
+        step has been taken, a `momentum_buffer` per parameter (copies of the slices of the flat buffer)."""
+        template = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-3).state_dict()['param_groups'][0]
+        g = self.param_groups[0]
+        group = dict(template)
+        group.update(lr=g['lr'], momentum=g['momentum'], weight_decay=g['weight_decay'], dampening=0, nesterov=False,
+                     params=list(range(len(self._params))))
+        state = {}
+        if self._steps > 0:
+            off = 0
+            for i, p in enumerate(self._params):
+                k = p.numel()
+                state[i] = {'momentum_buffer': self.flat_buf[off:off + k].view_as(p).clone()}
+                off += k
+        return {'state': state, 'param_groups': [group]}
+
+    def load_state_dict(self, state_dict):
+        """Accepts what FusedSGD.state_dict() or torch.optim.SGD(...).state_dict() produced for the same
+        parameter list (dampening 0, no nesterov -- the reference's configuration)."""
+        groups = state_dict['param_groups']
+        if len(groups) != 1 or len(groups[0]['params']) != len(self._params):
+            raise ValueError('FusedSGD.load_state_dict: expected one param group with %d parameters' % len(self._params))
+        g = groups[0]
+        if g.get('dampening', 0) != 0 or g.get('nesterov', False) or g.get('maximize', False):
+            raise ValueError('FusedSGD implements dampening 0, no nesterov, no maximize')
+        self.param_groups[0].update(lr=g['lr'], momentum=g['momentum'], weight_decay=g['weight_decay'])
+        state = state_dict.get('state', {})
+        have = [i for i in range(len(self._params)) if i in state and state[i].get('momentum_buffer') is not None]
+        if have and len(have) != len(self._params):
+            raise ValueError('FusedSGD.load_state_dict: momentum buffers for only some of the parameters')
+        with torch.no_grad():
+            if have:
+                off = 0
+                for i, p in enumerate(self._params):
+                    k = p.numel()
+                    buf = state[i]['momentum_buffer']
+                    if buf.numel() != k:
+                        raise ValueError('FusedSGD.load_state_dict: momentum buffer %d has the wrong size' % i)
+                    self.flat_buf[off:off + k].copy_(buf.reshape(-1).to(self.flat_buf.device, torch.float32))
+                    off += k
+                self._steps = max(self._steps, 1)   # next step uses momentum * buf + g
+            else:
+                self.flat_buf.zero_()
+                self._steps = 0                     # next step initialises the buffers with g, as torch does
+
     def zero_grad(self, set_to_none=False):
         # grads are views of flat_grad: zero in place, never detach them
         self.flat_grad.zero_()

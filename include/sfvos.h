@@ -218,6 +218,14 @@ int sfvos_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, flo
 /* x[i] *= s  (gradient averaging after the data-parallel all-reduce). */
 int sfvos_scale(float* x, int64_t n, float s, sfvos_stream_t stream);
 
+/* ---- evaluation-side reducer (reference code/helpers/davis_evaluate.py:40-42) ------------ */
+
+/* out[i] = OR over the n predicted masks of (masks[k][i] >= threshold), i < hw: the per-frame union the reference
+ * builds with numpy before writing the PNG.  masks: n contiguous fp32 planes of hw elements ([N,1,H,W]);
+ * out: hw bytes (0/1).  n may be 0 (all zeros).  Comparison and OR only: bit-exact with the reference. */
+int sfvos_mask_union(const float* masks, int n, int64_t hw, float threshold, unsigned char* out,
+                     sfvos_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -405,3 +405,21 @@ def test_bad_arguments_report_errors(lib):
     assert lib.load().sfvos_conv3d_stat_rows(ctypes.byref(d), None) < 0
     with pytest.raises(RuntimeError):
         lib.call('sfvos_scale', None, 10, 1.0, S())
+
+
+@pytest.mark.parametrize('n', [0, 1, 5])
+def test_mask_union_matches_the_reference_numpy_loop(lib, n):
+    """davis_evaluate.py:36-42: total = OR_k (mask_k >= 0.5)[0]; comparison + OR only -> bit-exact.  Values sit on
+    and around the threshold, including exactly 0.5."""
+    from sfvos_amd import union_mask
+    g = torch.Generator().manual_seed(8)
+    H, W = 37, 53
+    masks = torch.rand(n, 1, H, W, generator=g)
+    if n:
+        masks[0, 0, :4] = 0.5
+        masks[-1, 0, 4:8] = float(np.nextafter(np.float32(0.5), np.float32(0)))
+    total = np.zeros((H, W), dtype=bool)
+    for m in masks:                                  # the reference's loop, verbatim semantics
+        total = np.logical_or(total, (m.numpy() >= 0.5)[0])
+    got = union_mask(masks.cuda())
+    assert got.dtype == torch.bool and np.array_equal(got.cpu().numpy(), total)

@@ -303,3 +303,47 @@ def test_grouped_packed_clip_matches_ndhwc_and_returns_grouped_input_gradient():
     out3 = m.temporally_enhance_features(slow_bf, fast_bf)
     for k in out3:
         assert torch.equal(out3[k], res['grouped'][0][k]), k
+
+
+def test_optimizer_checkpoint_interchange_with_torch_sgd():
+    """FusedSGD.state_dict() / load_state_dict() use torch.optim.SGD's layout (reference train.py:117-121 saves it):
+    a run checkpointed by either optimiser resumes on the other with identical parameters afterwards."""
+    from sfvos_amd import FusedSGD
+
+    def grads(m, clip):
+        slow, fast = clip_inputs(1, 7, SMALL_LEVELS, clip, torch.device('cuda:0'))
+        proxy_loss(m.temporally_enhance_features(slow, fast)).backward()
+
+    def run(first, second):
+        m, dev = build(1, 7, 'fp32')
+        m.train()
+        make = {'torch': lambda ps: torch.optim.SGD(ps, lr=1e-2, momentum=0.9, weight_decay=1e-4),
+                'fused': lambda ps: FusedSGD(ps, lr=1e-2, momentum=0.9, weight_decay=1e-4)}
+        opt = make[first](list(m.parameters()))
+        opt.zero_grad()
+        grads(m, 0)
+        opt.step()
+        ckpt_model = {k: v.clone() for k, v in m.state_dict().items()}
+        ckpt_opt = opt.state_dict()
+        # resume in a fresh model with the other optimiser
+        m2, _ = build(1, 7, 'fp32')
+        m2.train()
+        m2.load_state_dict(ckpt_model)
+        opt2 = make[second](list(m2.parameters()))
+        opt2.load_state_dict(ckpt_opt)
+        opt2.zero_grad()
+        grads(m2, 1)
+        opt2.step()
+        return {k: v.detach().clone() for k, v in m2.named_parameters()}
+
+    ref = run('torch', 'torch')
+    for a, b in (('torch', 'fused'), ('fused', 'torch'), ('fused', 'fused')):
+        got = run(a, b)
+        for k in ref:
+            scale = float(ref[k].abs().max())
+            assert float((got[k] - ref[k]).abs().max()) <= 1e-5 * scale + 1e-9, (a, b, k)
+    # the saved dictionary itself has torch's keys
+    m, _ = build(1, 7, 'fp32')
+    sd = FusedSGD(m.parameters()).state_dict()
+    ref_keys = set(torch.optim.SGD(list(m.parameters()), lr=1e-3).state_dict()['param_groups'][0].keys())
+    assert set(sd['param_groups'][0].keys()) == ref_keys and sd['state'] == {}
