@@ -44,6 +44,8 @@ struct ConvLevels {
   int wg_begin[SFVOS_MAX_LEVELS + 1];   // first workgroup of each level
   int row_begin[SFVOS_MAX_LEVELS + 1];  // first statistics row of each level
   long long xpos[SFVOS_MAX_LEVELS];     // first position of the level in the x / y pyramid buffers
+  long long xbs[SFVOS_MAX_LEVELS];      // x: positions between consecutive clips / consecutive frames of the level
+  long long xfs[SFVOS_MAX_LEVELS];      //    (level-major: t_alloc*HW, HW; frame-major ring: HW, x_frame_stride)
   long long ypos[SFVOS_MAX_LEVELS];
 };
 
@@ -132,7 +134,8 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
   const int ncc = (CIN ? CIN : a.c_in) / CK;
   const long long HWp = (long long)H * W;
   // frame 0 of this clip inside the x buffer (t_alloc frames per clip, the conv's window starts at t_offset)
-  const char* xclip = a.x + (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset) * HWp) * a.x_pitch_bytes;
+  const long long xfs_bytes = a.lv.xfs[lvl] * a.x_pitch_bytes;  // bytes between consecutive frames of this level
+  const char* xclip = a.x + (a.lv.xpos[lvl] + b * a.lv.xbs[lvl]) * a.x_pitch_bytes + a.t_offset * xfs_bytes;
 
   f32x16 acc[TT][MT][NT];
 #pragma unroll
@@ -189,7 +192,7 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
     d.do_x = true;
     d.xrec = t_ok ? frame_bytes - (a.x_pitch_bytes > 64 ? cc * 64 : 0) : 0;  // frame outside the clip: all zeros
     d.xb = ring + slot * C::X_BYTES + lds_wave_off;
-    d.xsrc = xclip + (long long)(t_ok ? t : 0) * HWp * a.x_pitch_bytes + cc * a.x_chunk_bytes;
+    d.xsrc = xclip + (long long)(t_ok ? t : 0) * xfs_bytes + cc * a.x_chunk_bytes;
   };
   auto prep_w = [&](Dma& d, int cc, int dt, int tg, int s) {  // weight slice of stage s: [TPS taps][4 chunks][BN]
     d.do_w = true;
@@ -479,7 +482,8 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
   const int NF = TT + a.kt - 1;
   const int ncc = (CIN ? CIN : a.c_in) / CK;
   const long long HWp = (long long)H * W;
-  const char* xclip = a.x + (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset) * HWp) * a.x_pitch_bytes;
+  const long long xfs_bytes = a.lv.xfs[lvl] * a.x_pitch_bytes;  // bytes between consecutive frames of this level
+  const char* xclip = a.x + (a.lv.xpos[lvl] + b * a.lv.xbs[lvl]) * a.x_pitch_bytes + a.t_offset * xfs_bytes;
 
   f32x16 acc[M16 ? 1 : MT];   // 32x32 tiles: [row]
   f32x4 acc16[M16 ? MT : 1][2];  // 16x16 tiles: [row][channel half]
@@ -542,7 +546,7 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
     // frame outside the clip: empty descriptor, all zeros.  (pyramid NDHWC: the chunk offset sits inside the pixel)
     d.xrec = (unsigned)t < (unsigned)a.t_in ? frame_bytes - (a.x_pitch_bytes > 64 ? cc * 64 : 0) : 0;
     d.xb = ring + slot * C::X_BYTES + lds_wave_off;
-    d.xsrc = xclip + (long long)((unsigned)t < (unsigned)a.t_in ? t : 0) * HWp * a.x_pitch_bytes + cc * a.x_chunk_bytes;
+    d.xsrc = xclip + (long long)((unsigned)t < (unsigned)a.t_in ? t : 0) * xfs_bytes + cc * a.x_chunk_bytes;
   };
   auto prep_w = [&](Dma& d, int cc, int dt, int s) {  // weight slice of stage s: [9 taps][4 chunks][32]
     d.do_w = true;
@@ -979,6 +983,7 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
   SFVOS_REQUIRE(d->pad_t >= 0 && d->pad_t < d->kt + 1, "conv: bad pad_t %d", d->pad_t);
   const int ce = d->dtype == SFVOS_BF16 ? 8 : 4;
   SFVOS_REQUIRE(d->ld_y >= d->c_out, "conv: pitch smaller than channel count");
+  SFVOS_REQUIRE(d->x_frame_stride >= 0, "conv: negative x_frame_stride");
   if (d->x_group_stride != 0) {
     SFVOS_REQUIRE(d->dtype == SFVOS_BF16 && d->x_group_stride > 0 && d->x_group_stride % 8 == 0,
                   "conv: the channel-group-major x layout is bf16 only, stride a positive multiple of 8 elements");
@@ -1021,7 +1026,11 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
     lv.H[l] = H; lv.W[l] = W;
     lv.tiles_h[l] = ceil_div(H, p->TH); lv.tiles_w[l] = ceil_div(W, 32);
     lv.wg_begin[l] = (int)wg; lv.row_begin[l] = (int)rows;
-    lv.xpos[l] = (long long)d->batch * d->t_alloc * px;
+    if (d->x_frame_stride > 0) {  // frame-major ring: frame t of every level sits at position t * x_frame_stride
+      lv.xpos[l] = (long long)d->batch * px; lv.xbs[l] = (long long)H * W; lv.xfs[l] = d->x_frame_stride;
+    } else {
+      lv.xpos[l] = (long long)d->batch * d->t_alloc * px; lv.xbs[l] = (long long)d->t_alloc * H * W; lv.xfs[l] = (long long)H * W;
+    }
     lv.ypos[l] = (long long)d->batch * p->t_out * px;
     if (live) {
       // pixel tiles padded to groups of 8 (XCD-aware order in the kernel)
@@ -1113,7 +1122,8 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
   SFVOS_REQUIRE(!(stat_part && d->accumulate), "conv: statistics are those of the conv result; not available with accumulate");
   SFVOS_REQUIRE(d->ld_y % (d->dtype == SFVOS_BF16 ? 8 : 4) == 0, "conv: ld_y %d must be a multiple of a 16-byte chunk", d->ld_y);
   SFVOS_REQUIRE(!(d->taps == 1 && p.family == 2), "conv: 1x1 conv with c_out > 64 has no kernel instance");
-  if (!bias && !stat_part && d->taps == 1 && d->x_group_stride == 0 && !getenv("SFVOS_NO_LATERAL_KERNEL")) {
+  if (!bias && !stat_part && d->taps == 1 && d->x_group_stride == 0 && d->x_frame_stride == 0 &&
+      !getenv("SFVOS_NO_LATERAL_KERNEL")) {
     rc = lateral_dgrad_try(d, x, w_packed, y, (hipStream_t)stream);  // lateral data gradient: its own HBM-bound kernel
     if (rc >= 0) return rc;
   }

@@ -132,6 +132,10 @@ typedef struct sfvos_conv_desc {
                            * channel groups, element (position, c) at (c/32)*x_group_stride + position*32 + c%32
                            * (ld_x ignored): every 128-byte line a kernel touches is used whole, so the
                            * temporal re-reads of the input hit in L2 instead of fetching half-used lines. */
+  int64_t x_frame_stride; /* 0: x is level-major (all t_alloc frames of a level are consecutive).  > 0: x is a
+                           * FRAME-major ring (sequence inference): frame t of every level sits at position
+                           * t*x_frame_stride + B*sum_{l'<l} H_l'W_l' + (b*H_l+h)*W_l+w, so one frame of the whole
+                           * pyramid is one contiguous slot; sfvos_conv3d only (no weight gradient). */
 } sfvos_conv_desc;
 
 /* Partial-statistics rows ([2][c_out] fp32 each, one per workgroup tile) sfvos_conv3d writes for

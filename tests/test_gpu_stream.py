@@ -1,0 +1,79 @@
+"""GPU: sequence-mode inference with sliding-window reuse (sfvos_amd.SlowFastStream) against the
+module's own eval-mode temporally_enhance_features on every window of a short video, i.e. against what the
+reference's per-frame loop computes (code/helpers/model.py:316-340: window of fp frames around each frame, zero
+frames beyond the ends, model.py:215-225).  fp32: 1e-5 of the tensor scale and identical argmax; bf16: bit-identical
+(same kernels, same operands, same summation order)."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import SMALL_LEVELS
+from oracle.closed_form import closed_form_features, closed_form_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def build(sp, fp, precision):
+    from sfvos_amd import SlowFastLayers
+    dev = torch.device('cuda:0')
+    m = SlowFastLayers(256, dev, sp, fp, precision=precision)
+    m.load_state_dict(closed_form_state_dict(m))
+    return m.to(dev).eval(), dev
+
+
+def reference_windows(m, frames, sp, fp):
+    """What the reference loop feeds the module for each centre frame, and what it gets back."""
+    N = len(frames)
+    outs = []
+    zero = OrderedDict((k, torch.zeros_like(v)) for k, v in frames[0].items())
+    with torch.no_grad():
+        for i in range(N):
+            idx = range(i - fp // 2, i - fp // 2 + fp)
+            win = [frames[j] if 0 <= j < N else zero for j in idx]
+            fast = OrderedDict((k, torch.stack([w[k] for w in win])) for k in frames[0])        # [fp,256,H,W]
+            c = fp // 2
+            slow = OrderedDict((k, v[c - sp // 2: c + (sp + 1) // 2]) for k, v in fast.items())
+            outs.append(m.temporally_enhance_features([slow], [fast]))
+    return outs
+
+
+@pytest.mark.parametrize('sp,fp,precision', [(3, 7, 'fp32'), (1, 1, 'fp32'), (1, 7, 'bf16'), (4, 32, 'bf16'),
+                                             (7, 7, 'fp32')])
+def test_stream_equals_per_window_recompute(sp, fp, precision):
+    from sfvos_amd import SlowFastStream
+    m, dev = build(sp, fp, precision)
+    N = 5 if fp < 32 else 3
+    seq = closed_form_features(N, SMALL_LEVELS, clip=11)                      # level -> [N,256,H,W]
+    frames = [OrderedDict((k, v[i].to(dev)) for k, v in seq.items()) for i in range(N)]
+    ref = reference_windows(m, frames, sp, fp)
+    stream = SlowFastStream(m, list(SMALL_LEVELS.values()), keys=list(SMALL_LEVELS.keys()))
+    got = stream.run_sequence(frames)
+    assert len(got) == N
+    for i in range(N):
+        for k in ref[i]:
+            a, b = got[i][k], ref[i][k]
+            assert a.shape == b.shape and a.dtype == torch.float32
+            if precision == 'bf16':
+                assert torch.equal(a, b), (i, k)
+            else:
+                scale = float(b.abs().max())
+                assert float((a - b).abs().max()) <= 1e-5 * scale, (i, k)
+                assert torch.equal(a.argmax(1), b.argmax(1))
+    # a second sequence through the same object (reset) gives the same answers
+    again = stream.run_sequence(frames)
+    for i in range(N):
+        for k in ref[i]:
+            assert torch.equal(again[i][k], got[i][k])
+
+
+def test_stream_refuses_train_mode_and_cpu():
+    from sfvos_amd import SlowFastLayers, SlowFastStream
+    m, dev = build(1, 1, 'fp32')
+    s = SlowFastStream(m, list(SMALL_LEVELS.values()), keys=list(SMALL_LEVELS.keys()))
+    m.train()
+    with pytest.raises(RuntimeError):
+        s.push(None)
+    with pytest.raises(RuntimeError):
+        SlowFastStream(SlowFastLayers(256, torch.device('cpu'), 1, 1), [(4, 4)])
