@@ -28,7 +28,7 @@ class ConvDesc(C.Structure):
     """Mirror of sfvos_conv_desc (include/sfvos.h)."""
     _fields_ = [('dtype', i32), ('batch', i32), ('t_in', i32), ('t_alloc', i32), ('t_offset', i32), ('c_in', i32),
                 ('c_out', i32), ('kt', i32), ('taps', i32), ('pad_t', i32), ('ld_x', i32), ('ld_y', i32),
-                ('accumulate', i32), ('pyr', Pyramid), ('x_group_stride', i64), ('x_frame_stride', i64)]
+                ('accumulate', i32), ('pyr', Pyramid), ('x_group_stride', i64), ('x_frame_stride', i64), ('y_frame_stride', i64)]
 
 
 def make_pyramid(shapes):

@@ -47,6 +47,8 @@ struct ConvLevels {
   long long xbs[SFVOS_MAX_LEVELS];      // x: positions between consecutive clips / consecutive frames of the level
   long long xfs[SFVOS_MAX_LEVELS];      //    (level-major: t_alloc*HW, HW; frame-major ring: HW, x_frame_stride)
   long long ypos[SFVOS_MAX_LEVELS];
+  long long ybs[SFVOS_MAX_LEVELS];      // y: positions between consecutive clips / frames (as xbs / xfs)
+  long long yfs[SFVOS_MAX_LEVELS];
 };
 
 struct ConvArgs {
@@ -333,7 +335,8 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
   float s1[NT], s2[NT];
 #pragma unroll
   for (int q = 0; q < NT; ++q) s1[q] = s2[q] = 0.f;
-  T* yclip = (T*)a.y + (a.lv.ypos[lvl] + (long long)b * a.t_out * HWp) * a.ld_y;
+  T* yclip = (T*)a.y + (a.lv.ypos[lvl] + b * a.lv.ybs[lvl]) * a.ld_y;
+  const long long yfs = a.lv.yfs[lvl];
   __syncthreads();  // every wave has finished reading the ring / weight buffers
   float* scr = (float*)smem + wv * (32 * 33);  // [32 px][32 ch], rows padded to 33 floats
   constexpr int CPP = 32 / CE;                  // 16-byte output chunks per pixel of a tile
@@ -357,7 +360,7 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
           scr[px * 33 + r] = v;
           if (w0 + px < W) { s1[q] += v; s2[q] += v * v; }
         }
-        T* yrow = yclip + ((long long)(to * H + h) * W + w0) * a.ld_y + nbase;
+        T* yrow = yclip + (to * yfs + (long long)h * W + w0) * a.ld_y + nbase;
 #pragma unroll
         for (int it = 0; it < (32 * CPP) / 64; ++it) {
           const int idx = it * 64 + lane, px = idx / CPP, ch = (idx % CPP) * CE;
@@ -699,7 +702,8 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
 #endif
   float s1 = 0.f, s2 = 0.f;  // per-lane partial statistics of channel r (32x32) / channels p16, 16+p16 (16x16)
   float s1b = 0.f, s2b = 0.f;
-  T* yclip = (T*)a.y + (a.lv.ypos[lvl] + (long long)b * a.t_out * HWp) * a.ld_y;
+  T* yclip = (T*)a.y + (a.lv.ypos[lvl] + b * a.lv.ybs[lvl]) * a.ld_y;
+  const long long yfs = a.lv.yfs[lvl];
   const int to = tb0 + jf;
   __syncthreads();  // ring / weight buffers are dead
   if constexpr (M16) {
@@ -725,7 +729,7 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
 #pragma unroll
         for (int u = 0; u < 8; ++u) f[u] = scr[px * 33 + ch + u];
         if (w0 + kh * 16 + px < W) {
-          T* dst = yclip + ((long long)(to * H + h) * W + w0 + kh * 16 + px) * a.ld_y + ch;
+          T* dst = yclip + (to * yfs + (long long)h * W + w0 + kh * 16 + px) * a.ld_y + ch;
           if (a.accumulate) {
             const u32x4 old = *(const u32x4*)dst;
             T oldv[8];
@@ -794,7 +798,7 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
           scr[px * 33 + r] = v;
           if (w0 + px < W) { s1 += v; s2 += v * v; }
         }
-        T* yrow = yclip + ((long long)(to * H + h) * W + w0) * a.ld_y;
+        T* yrow = yclip + (to * yfs + (long long)h * W + w0) * a.ld_y;
   #pragma unroll
         for (int it = 0; it < (32 * CPP) / 64; ++it) {
           const int idx = it * 64 + lane, px = idx / CPP, ch = (idx % CPP) * CE;
@@ -983,7 +987,7 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
   SFVOS_REQUIRE(d->pad_t >= 0 && d->pad_t < d->kt + 1, "conv: bad pad_t %d", d->pad_t);
   const int ce = d->dtype == SFVOS_BF16 ? 8 : 4;
   SFVOS_REQUIRE(d->ld_y >= d->c_out, "conv: pitch smaller than channel count");
-  SFVOS_REQUIRE(d->x_frame_stride >= 0, "conv: negative x_frame_stride");
+  SFVOS_REQUIRE(d->x_frame_stride >= 0 && d->y_frame_stride >= 0, "conv: negative frame stride");
   if (d->x_group_stride != 0) {
     SFVOS_REQUIRE(d->dtype == SFVOS_BF16 && d->x_group_stride > 0 && d->x_group_stride % 8 == 0,
                   "conv: the channel-group-major x layout is bf16 only, stride a positive multiple of 8 elements");
@@ -1031,7 +1035,11 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
     } else {
       lv.xpos[l] = (long long)d->batch * d->t_alloc * px; lv.xbs[l] = (long long)d->t_alloc * H * W; lv.xfs[l] = (long long)H * W;
     }
-    lv.ypos[l] = (long long)d->batch * p->t_out * px;
+    if (d->y_frame_stride > 0) {
+      lv.ypos[l] = (long long)d->batch * px; lv.ybs[l] = (long long)H * W; lv.yfs[l] = d->y_frame_stride;
+    } else {
+      lv.ypos[l] = (long long)d->batch * p->t_out * px; lv.ybs[l] = (long long)p->t_out * H * W; lv.yfs[l] = (long long)H * W;
+    }
     if (live) {
       // pixel tiles padded to groups of 8 (XCD-aware order in the kernel)
       wg += (long long)d->batch * p->n_blocks * ceil_div(lv.tiles_h[l] * lv.tiles_w[l], 8) * 8;  // x blocks per launch
@@ -1123,7 +1131,7 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
   SFVOS_REQUIRE(d->ld_y % (d->dtype == SFVOS_BF16 ? 8 : 4) == 0, "conv: ld_y %d must be a multiple of a 16-byte chunk", d->ld_y);
   SFVOS_REQUIRE(!(d->taps == 1 && p.family == 2), "conv: 1x1 conv with c_out > 64 has no kernel instance");
   if (!bias && !stat_part && d->taps == 1 && d->x_group_stride == 0 && d->x_frame_stride == 0 &&
-      !getenv("SFVOS_NO_LATERAL_KERNEL")) {
+      d->y_frame_stride == 0 && !getenv("SFVOS_NO_LATERAL_KERNEL")) {
     rc = lateral_dgrad_try(d, x, w_packed, y, (hipStream_t)stream);  // lateral data gradient: its own HBM-bound kernel
     if (rc >= 0) return rc;
   }

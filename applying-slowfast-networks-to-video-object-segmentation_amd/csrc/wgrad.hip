@@ -419,7 +419,8 @@ static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
   SFVOS_REQUIRE(d->taps == 9 || d->taps == 1, "wgrad: taps must be 9 or 1");
   SFVOS_REQUIRE(d->c_in % 32 == 0 && d->c_out % 32 == 0 && d->c_in > 0 && d->c_out > 0, "wgrad: channels % 32");
   SFVOS_REQUIRE(d->pad_t == 0, "wgrad: only forward convs (pad_t == 0) have a weight gradient here");
-  SFVOS_REQUIRE(d->x_frame_stride == 0, "wgrad: frame-major ring buffers are an inference-only input layout");
+  SFVOS_REQUIRE(d->x_frame_stride == 0 && d->y_frame_stride == 0,
+                "wgrad: frame-major ring buffers are an inference-only layout");
   const int ce = d->dtype == SFVOS_BF16 ? 8 : 4;
   SFVOS_REQUIRE(d->ld_y % ce == 0 && d->ld_y >= d->c_out, "wgrad: pitch");
   if (d->x_group_stride != 0)

@@ -226,7 +226,7 @@ class SlowFastLayers(nn.Module):
     def _desc(self, layer, B, pyr, dt_id, ld_x, ld_y, t_alloc=None, t_offset=0, dgrad=False, accumulate=0):
         """ld_x: pitch of x in elements, or the x tensor itself ([M, ld] ndhwc / [G, M, 32] grouped)."""
         d = _lib.ConvDesc()
-        d.x_group_stride = d.x_frame_stride = 0
+        d.x_group_stride = d.x_frame_stride = d.y_frame_stride = 0
         if torch.is_tensor(ld_x):
             if ld_x.dim() == 3:
                 d.x_group_stride, ld_x = ld_x.shape[1] * 32, 32

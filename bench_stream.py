@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--fp', type=int, default=32)
     ap.add_argument('--frames', type=int, default=40, help='timed frames (after the pipeline is full)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--chunk', type=int, default=4, help='frames per push_many() call of the chunked run')
     args = ap.parse_args()
     from sfvos_amd import PackedClip, SlowFastLayers, SlowFastStream, davis_pyramid
     dev = torch.device('cuda', 0)
@@ -39,18 +40,23 @@ def main():
     pool = [OrderedDict((k, torch.randn((256, h, w), generator=gen, device=dev)) for k, (h, w) in pyr)
             for _ in range(4)]   # a few distinct frames, cycled
 
-    stream = SlowFastStream(model, shapes, keys=keys)
+    res = {}
     with torch.no_grad():
-        for i in range(args.fp + 2):          # fill the pipeline (+ warm-up)
-            stream.push(pool[i % len(pool)])
-        torch.cuda.synchronize()
-        t0 = time.time()
-        for i in range(args.frames):
-            out = stream.push(pool[i % len(pool)])
-        torch.cuda.synchronize()
-        dt_stream = (time.time() - t0) / args.frames
-        assert out is not None
-
+        for chunk in (1, args.chunk):
+            stream = SlowFastStream(model, shapes, keys=keys, chunk=chunk)
+            fill = ((args.fp + 2 + chunk - 1) // chunk) * chunk
+            for i in range(0, fill, chunk):          # fill the pipeline (+ warm-up)
+                stream.push_many([pool[(i + j) % len(pool)] for j in range(chunk)])
+            torch.cuda.synchronize()
+            nfr = (args.frames // chunk) * chunk
+            t0 = time.time()
+            for i in range(0, nfr, chunk):
+                out = stream.push_many([pool[(i + j) % len(pool)] for j in range(chunk)])
+            torch.cuda.synchronize()
+            res[chunk] = (time.time() - t0) / nfr
+            assert len(out) == chunk
+            del stream
+        dt_stream = res[1]
         # per-frame recompute: the whole window through the module (channels-last hand-over, forward only)
         tdt = torch.bfloat16 if args.precision == 'bf16' else torch.float32
         levels = [torch.randn((1, args.fp, h, w, 256), generator=gen, device=dev).to(tdt) for _, (h, w) in pyr]
@@ -72,10 +78,12 @@ def main():
         'metric': 'frames/sec, sequence inference (T=%d window, 480x854)' % args.fp, 'unit': 'frames/s',
         'stream': {'value': round(1.0 / dt_stream, 2), 'ms_per_frame': round(1e3 * dt_stream, 3),
                    'gflop_per_frame': round(flops_stream / 1e9, 1)},
+        'stream_chunked': {'chunk': args.chunk, 'value': round(1.0 / res[args.chunk], 2),
+                           'ms_per_frame': round(1e3 * res[args.chunk], 3)},
         'recompute_window_per_frame': {'value': round(1.0 / dt_full, 2), 'ms_per_frame': round(1e3 * dt_full, 3),
                                        'gflop_per_frame': round(plan.forward_flops(P) / 1e9, 1),
                                        'note': 'window already channels-last on the GPU; the reference also restacks it'},
-        'speedup': round(dt_full / dt_stream, 2), 'dtype': args.precision, 'data': 'synthetic',
+        'speedup': round(dt_full / dt_stream, 2), 'speedup_chunked': round(dt_full / res[args.chunk], 2), 'dtype': args.precision, 'data': 'synthetic',
         'config': {'workload': 'SlowFastLayers (sp=%d, fp=%d) eval forward per video frame, 5 FPN levels (P=%d)'
                                % (args.sp, args.fp, P)}}))
 

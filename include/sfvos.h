@@ -136,6 +136,8 @@ typedef struct sfvos_conv_desc {
                            * FRAME-major ring (sequence inference): frame t of every level sits at position
                            * t*x_frame_stride + B*sum_{l'<l} H_l'W_l' + (b*H_l+h)*W_l+w, so one frame of the whole
                            * pyramid is one contiguous slot; sfvos_conv3d only (no weight gradient). */
+  int64_t y_frame_stride; /* the same for y: 0 level-major, > 0 frame-major (output frame t of every level at
+                           * position t*y_frame_stride + ...): consecutive output frames are whole-pyramid slots. */
 } sfvos_conv_desc;
 
 /* Partial-statistics rows ([2][c_out] fp32 each, one per workgroup tile) sfvos_conv3d writes for

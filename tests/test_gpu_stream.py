@@ -39,16 +39,17 @@ def reference_windows(m, frames, sp, fp):
     return outs
 
 
-@pytest.mark.parametrize('sp,fp,precision', [(3, 7, 'fp32'), (1, 1, 'fp32'), (1, 7, 'bf16'), (4, 32, 'bf16'),
-                                             (7, 7, 'fp32')])
-def test_stream_equals_per_window_recompute(sp, fp, precision):
+@pytest.mark.parametrize('sp,fp,precision,chunk', [(3, 7, 'fp32', 1), (1, 1, 'fp32', 2), (1, 7, 'bf16', 1),
+                                                   (4, 32, 'bf16', 1), (7, 7, 'fp32', 3), (3, 7, 'bf16', 4),
+                                                   (4, 32, 'bf16', 4), (3, 7, 'fp32', 5)])
+def test_stream_equals_per_window_recompute(sp, fp, precision, chunk):
     from sfvos_amd import SlowFastStream
     m, dev = build(sp, fp, precision)
-    N = 5 if fp < 32 else 3
+    N = 7 if fp < 32 else 5
     seq = closed_form_features(N, SMALL_LEVELS, clip=11)                      # level -> [N,256,H,W]
     frames = [OrderedDict((k, v[i].to(dev)) for k, v in seq.items()) for i in range(N)]
     ref = reference_windows(m, frames, sp, fp)
-    stream = SlowFastStream(m, list(SMALL_LEVELS.values()), keys=list(SMALL_LEVELS.keys()))
+    stream = SlowFastStream(m, list(SMALL_LEVELS.values()), keys=list(SMALL_LEVELS.keys()), chunk=chunk)
     got = stream.run_sequence(frames)
     assert len(got) == N
     for i in range(N):

@@ -107,7 +107,7 @@ def test_cabi_library_exports_every_declared_symbol():
     lib.sfvos_version.restype = ctypes.c_int
     assert lib.sfvos_version() >= 100
     # struct mirrors: sizes must match the C structs (13 ints + sfvos_pyramid{int, int[8], int[8]})
-    assert ctypes.sizeof(_lib.Pyramid) == 68 and ctypes.sizeof(_lib.ConvDesc) == 136
+    assert ctypes.sizeof(_lib.Pyramid) == 68 and ctypes.sizeof(_lib.ConvDesc) == 144
     assert ctypes.sizeof(_lib.Levels) == 72
 
 
