@@ -531,6 +531,11 @@ class SlowFastLayers(nn.Module):
                         _lib.call('sfvos_conv3d_wgrad', ctypes.byref(w['wd']), _ptr(w['src']), _ptr(dx), _ptr(w['gw']),
                                   sacc if (l.conv + '.weight') in direct else 0, _ptr(w['ws']), _ptr(zeros), st)
                     grads[l.conv + '.weight'] = w['gw']
+                if sink is not None:  # this layer's slice of the flat gradient is complete: exchange may start
+                    done = [q for q in list(conv.parameters()) + list(bn.parameters())]
+                    if all((n_ in direct) for n_ in ([l.conv + '.weight', l.bn + '.weight', l.bn + '.bias']
+                                                     + ([l.conv + '.bias'] if conv.bias is not None else []))):
+                        sink.layer_done(done, stream)
         if side is not None:
             main.wait_stream(side)
         del keepalive  # workspaces are released only after the join

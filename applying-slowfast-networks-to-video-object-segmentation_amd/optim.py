@@ -32,9 +32,12 @@ class FusedSGD(torch.optim.Optimizer):
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_buf = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
+        self._span = {}   # id(param) -> [lo, hi) of the flat buffers
+        self.bucket = None
         with torch.no_grad():
             for p in params:
                 k = p.numel()
+                self._span[id(p)] = (off, off + k)
                 self.flat_param[off:off + k].copy_(p.reshape(-1))
                 p.data = self.flat_param[off:off + k].view_as(p)
                 p.grad = self.flat_grad[off:off + k].view_as(p)
@@ -43,13 +46,30 @@ class FusedSGD(torch.optim.Optimizer):
         self._views = {id(p): p.grad for p in params}
         self._clean = False  # True between zero_grad() and the first gradient written after it
 
-    def attach(self, module):
+    def attach(self, module, bucket=None):
         """Let `module` (a SlowFastLayers) write its parameter gradients straight into the flat gradient buffer
         (overwrite on the first backward after zero_grad(), accumulate in place on later ones): no per-parameter
         temporaries and no `grad += tmp` launches.  dgamma/dbeta of a BatchNorm share one kernel, so both or neither
-        of them must be FusedSGD parameters (always true for SlowFastLayers.parameters())."""
+        of them must be FusedSGD parameters (always true for SlowFastLayers.parameters()).
+        bucket: a GradBucket over self.flat_grad; when it is armed, every layer's slice of the flat gradient is
+        all-reduced as soon as backward has produced it (overlap of the exchange with the rest of backward)."""
         module._grad_sink = self
+        self.bucket = bucket
         return self
+
+    def layer_done(self, params, stream=None):
+        """Called by the module's backward when every gradient of `params` (one layer: conv + its BatchNorm) has
+        been enqueued on `stream`: hands the smallest covering range of the flat gradient to the armed bucket."""
+        b = getattr(self, 'bucket', None)
+        if b is None or not b.armed:
+            return
+        spans = [self._span[id(p)] for p in params if id(p) in self._span]
+        if not spans:
+            return
+        lo, hi = min(s[0] for s in spans), max(s[1] for s in spans)
+        if hi - lo != sum(s[1] - s[0] for s in spans):
+            return   # not contiguous in the flat buffer: left for GradBucket.finish()
+        b.segment_ready(lo, hi, stream)
 
     # -- gradient-sink protocol used by SlowFastLayers._engine_backward
     def begin_direct(self, device):

@@ -4,8 +4,9 @@
 The reference's SlowFast path is single-process; clips are independent units,
 so they shard across ranks with ONE exchange step per optimiser step: the all-reduce(sum) of the
 flat gradient bucket (3.9 M fp32 at (sp,fp)=(4,32)), averaged by world size.  The collective
-is issued on a side stream as soon as backward has produced the last gradient and the optimiser
-waits on its event, so it overlaps with whatever the caller runs next on the compute stream.
+runs on a side stream, layer by layer as backward finishes each layer's gradients (layer 3 and
+the second lateral first), so all but the first layer's share overlaps with the rest of backward;
+the optimiser waits for it.
 BatchNorm statistics stay per replica (the reference has no SyncBN)."""
 import os
 
@@ -33,33 +34,80 @@ class GradBucket(object):
     """All-reduce + average of one flat gradient tensor.
 
     `flat_grad` is FusedSGD.flat_grad (or any 1-D fp32 tensor the parameters' .grad alias).
-    start() launches the collective (side stream on GPU), finish() makes the current stream
-    wait for it and applies the 1/world scaling."""
+
+    Whole-buffer use:  all_reduce()  (= start() + finish()) after backward.
+
+    Overlapped with backward: arm() before the backward whose gradients are to be exchanged; the
+    producer of the gradients then reports every finished contiguous range with segment_ready(lo, hi) -- FusedSGD.attach
+    (module, bucket) makes SlowFastLayers' backward do that layer by layer, on the stream the weight-gradient kernels
+    ran on -- and each range is all-reduced at once on a side stream (RCCL over xGMI) while backward continues with the
+    earlier layers; finish() waits for the collectives, reduces whatever was not reported, and applies 1/world."""
 
     def __init__(self, flat_grad, group=None):
         self.flat = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self._work = None
+        self._works = []
         self._stream = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
-        self._event = None
+        self._armed = False
+        self._sent = []      # [lo, hi) ranges already handed to the collective since arm()
 
+    # -- whole buffer -------------------------------------------------------------------------------------
     def start(self):
         if self.world == 1:
             return
+        self._armed = False
+        self._launch(0, self.flat.numel())
+
+    def _launch(self, lo, hi, producer_stream=None):
+        part = self.flat[lo:hi]
         if self._stream is not None:
-            self._stream.wait_stream(torch.cuda.current_stream())
+            self._stream.wait_stream(producer_stream if producer_stream is not None else torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
-                self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._works.append(dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
-            self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._works.append(dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._sent.append((lo, hi))
+
+    # -- overlapped with backward -------------------------------------------------------------------------
+    def arm(self):
+        """The next backward produces the gradients to exchange: accept segment_ready() calls."""
+        self._armed = self.world > 1
+        self._sent = []
+
+    @property
+    def armed(self):
+        return self._armed
+
+    def segment_ready(self, lo, hi, producer_stream=None):
+        """flat[lo:hi] is final (every kernel writing it has been enqueued on producer_stream / the current stream)."""
+        if not self._armed or hi <= lo:
+            return
+        for a, b in self._sent:
+            if lo < b and a < hi:
+                raise RuntimeError('GradBucket: range [%d, %d) reported twice' % (lo, hi))
+        self._launch(lo, hi, producer_stream)
 
     def finish(self):
         if self.world == 1:
             return
-        if self._work is not None:
-            self._work.wait()
-            self._work = None
+        if self._armed or self._sent:
+            # whatever backward did not report (parameters outside the module, or no gradient sink attached)
+            covered = sorted(self._sent)
+            pos, gaps = 0, []
+            for a, b in covered:
+                if a > pos:
+                    gaps.append((pos, a))
+                pos = max(pos, b)
+            if pos < self.flat.numel():
+                gaps.append((pos, self.flat.numel()))
+            for a, b in gaps:
+                self._launch(a, b)
+        self._armed = False
+        self._sent = []
+        for w in self._works:
+            w.wait()
+        self._works = []
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
             import ctypes

@@ -101,9 +101,11 @@ def main():
     model.train()
     model.n_streams = args.streams
     opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
-    if not args.no_grad_sink:
-        opt.attach(model)   # kernels write parameter gradients straight into the flat gradient buffer
     bucket = GradBucket(opt.flat_grad)
+    if not args.no_grad_sink:
+        # kernels write parameter gradients straight into the flat gradient buffer; with world > 1 each layer's
+        # slice is all-reduced (RCCL, side stream) as soon as backward has produced it
+        opt.attach(model, bucket)
     tdt = torch.bfloat16 if args.precision == 'bf16' else torch.float32
     pyr = davis_pyramid()
     P = sum(h * w for _, (h, w) in pyr)
@@ -120,9 +122,12 @@ def main():
 
     def step(i):
         out = model.enhance_packed(clip)
-        proxy_loss(out).backward()
-        if i % 2 == 1:  # model.py:372-374: optimiser every 2nd clip
-            bucket.all_reduce()
+        loss = proxy_loss(out)
+        if i % 2 == 1:  # model.py:372-374: optimiser every 2nd clip: this backward completes the gradients
+            bucket.arm()
+        loss.backward()
+        if i % 2 == 1:
+            bucket.finish()
             opt.step()
             opt.zero_grad()
 

@@ -37,7 +37,7 @@ def _worker(rank, world, port, q):
             bucket.all_reduce()
             results.append(flat.clone())
             flat.zero_()
-    q.put((rank, results))
+    q.put((rank, [r.numpy() for r in results]))   # by value: the sender may exit before the parent reads
     dist.barrier()
     dist.destroy_process_group()
 
@@ -50,6 +50,7 @@ def test_grad_bucket_allreduce_world2():
     for p in procs:
         p.start()
     got = dict(q.get(timeout=120) for _ in range(world))
+    got = {r: [torch.from_numpy(a) for a in v] for r, v in got.items()}
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -64,3 +65,48 @@ def test_grad_bucket_allreduce_world2():
         for rank in range(world):
             assert torch.allclose(got[rank][k], want, atol=1e-6)
     assert torch.equal(got[0][0], got[1][0])
+
+
+def _worker_segments(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from sfvos_amd import GradBucket, init_distributed
+    init_distributed('gloo')
+    n = 4096
+    flat = torch.randn(n, generator=torch.Generator().manual_seed(50 + rank))
+    local = flat.clone()
+    bucket = GradBucket(flat)
+    bucket.arm()
+    assert bucket.armed
+    # ranges reported in the order backward finishes its layers (last layer first), one range never reported
+    for lo, hi in ((3000, 4096), (1200, 3000), (0, 700)):
+        bucket.segment_ready(lo, hi)
+    try:
+        bucket.segment_ready(600, 800)
+        overlap_refused = False
+    except RuntimeError:
+        overlap_refused = True
+    bucket.finish()                       # reduces the unreported [700, 1200) too, then scales
+    assert not bucket.armed
+    q.put((rank, local.numpy(), flat.clone().numpy(), overlap_refused))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_bucket_segments_overlap_api_world2():
+    """arm() / segment_ready() / finish(): the per-layer exchange backward drives must give the same result as
+    one all-reduce of the whole buffer, whatever the order and whatever is left unreported."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_segments, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    want = sum(torch.from_numpy(g[1]) for g in got) / world
+    for rank, _, reduced, refused in got:
+        assert refused
+        assert torch.allclose(torch.from_numpy(reduced), want, atol=1e-6)
