@@ -21,7 +21,7 @@ struct FinalizeTab {
 
 constexpr int BNB_THREADS = 256;
 constexpr int BNB_POS = 512;      // positions per block iteration
-constexpr int BNB_MAX_ROWS = 2048;  // per level
+constexpr int BNB_MAX_ROWS = 1024;  // per level
 
 static int make_level_tab(const sfvos_levels* lv, LevelTab* t, const char* what) {
   SFVOS_REQUIRE(lv != nullptr && lv->n_levels >= 1 && lv->n_levels <= SFVOS_MAX_LEVELS, "%s: bad level count", what);
@@ -161,24 +161,41 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_bwd_kernel(
   if (rowl < rl) {
     for (long long pb = m_begin + (long long)bi * BNB_POS; pb < m_end; pb += (long long)nblk * BNB_POS) {
       const long long pend = pb + BNB_POS < m_end ? pb + BNB_POS : m_end;
-      for (long long m = pb + rowl; m < pend; m += rl) {
-        float fdy[CE], fx[CE];
-        unpack<DT>(*(const u32x4*)(dy + (m * ld_dy + c) * ES), fdy);
-        unpack<DT>(*(const u32x4*)(x + (m * ld_x + c) * ES), fx);
-        float out[CE];
+      // UN positions per trip: all their loads are issued before the first use (memory-level parallelism;
+      // the per-channel sums still add the positions in ascending order)
+      constexpr int UN = 4;
+      for (long long m0 = pb + rowl; m0 < pend; m0 += (long long)UN * rl) {
+        u32x4 rdy[UN], rx[UN];
 #pragma unroll
-        for (int e = 0; e < CE; ++e) {
-          const float dz = (relu && !(fx[e] * sc[e] + sh[e] > 0.f)) ? 0.f : fdy[e];
-          if (APPLY) {
-            const float d = p0[e] * dz + p1[e] * fx[e] + p2[e];
-            out[e] = d;
-            a0[e] += d;
-          } else {
-            a0[e] += dz;
-            a1[e] += dz * ((fx[e] - p0[e]) * p1[e]);
+        for (int u = 0; u < UN; ++u) {
+          const long long m = m0 + (long long)u * rl;
+          if (m < pend) {
+            rdy[u] = *(const u32x4*)(dy + (m * ld_dy + c) * ES);
+            rx[u] = *(const u32x4*)(x + (m * ld_x + c) * ES);
           }
         }
-        if (APPLY) *(u32x4*)(dx + (m * ld_dx + c) * ES) = pack<DT>(out);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const long long m = m0 + (long long)u * rl;
+          if (m >= pend) break;
+          float fdy[CE], fx[CE];
+          unpack<DT>(rdy[u], fdy);
+          unpack<DT>(rx[u], fx);
+          float out[CE];
+#pragma unroll
+          for (int e = 0; e < CE; ++e) {
+            const float dz = (relu && !(fx[e] * sc[e] + sh[e] > 0.f)) ? 0.f : fdy[e];
+            if (APPLY) {
+              const float d = p0[e] * dz + p1[e] * fx[e] + p2[e];
+              out[e] = d;
+              a0[e] += d;
+            } else {
+              a0[e] += dz;
+              a1[e] += dz * ((fx[e] - p0[e]) * p1[e]);
+            }
+          }
+          if (APPLY) *(u32x4*)(dx + (m * ld_dx + c) * ES) = pack<DT>(out);
+        }
       }
     }
   }
