@@ -347,3 +347,22 @@ def test_optimizer_checkpoint_interchange_with_torch_sgd():
     sd = FusedSGD(m.parameters()).state_dict()
     ref_keys = set(torch.optim.SGD(list(m.parameters()), lr=1e-3).state_dict()['param_groups'][0].keys())
     assert set(sd['param_groups'][0].keys()) == ref_keys and sd['state'] == {}
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_batch_of_two_clips_equals_two_single_clip_calls_in_eval(precision):
+    """B = 2 (the reference always passes lists of length 1, but the API takes any B): in eval mode the clips of a
+    batch do not interact, so each must come out exactly as if it had been passed alone -- both input layouts."""
+    sp, fp = 3, 7
+    m, dev = build(sp, fp, precision)
+    m.eval()
+    s0, f0 = clip_inputs(sp, fp, SMALL_LEVELS, 0, dev)
+    s1, f1 = clip_inputs(sp, fp, SMALL_LEVELS, 1, dev)
+    with torch.no_grad():
+        both = m.temporally_enhance_features(s0 + s1, f0 + f1)
+        one0 = m.temporally_enhance_features(s0, f0)
+        one1 = m.temporally_enhance_features(s1, f1)
+    for k in both:
+        assert both[k].shape[0] == 2
+        assert torch.equal(both[k][0:1], one0[k]), k
+        assert torch.equal(both[k][1:2], one1[k]), k
