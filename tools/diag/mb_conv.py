@@ -1,0 +1,103 @@
+"""micro-bench of sfvos_conv3d / wgrad on the headline shapes (whole DAVIS pyramid, bf16)"""
+import ctypes
+import os
+import sys
+
+import torch
+
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from sfvos_amd import _lib, davis_pyramid  # noqa: E402
+
+P = lambda t: ctypes.c_void_p(t.data_ptr())
+S = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+SHAPES = [s for _, s in davis_pyramid()]
+
+
+def desc(T, cin, cout, kt, taps, pad_t=0, shapes=SHAPES):
+    d = _lib.ConvDesc()
+    d.dtype, d.batch, d.t_in, d.t_alloc, d.t_offset = _lib.BF16, 1, T, T, 0
+    d.c_in, d.c_out, d.kt, d.taps, d.pad_t, d.ld_x, d.ld_y, d.accumulate = cin, cout, kt, taps, pad_t, cin, cout, 0
+    d.pyr = _lib.make_pyramid(shapes)
+    return d, T + 2 * pad_t - kt + 1
+
+
+def timeit(f, reps):
+    f(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def conv(name, T, cin, cout, kt, taps, pad_t=0, reps=5, shapes=SHAPES, acc=0):
+    d, t_out = desc(T, cin, cout, kt, taps, pad_t, shapes)
+    d.accumulate = acc
+    pix = sum(h * w for h, w in shapes)
+    x = torch.randn(T * pix, cin, device='cuda').bfloat16()
+    wp = (torch.randn(cout * cin * kt * taps, device='cuda') * 0.02).bfloat16()
+    y = torch.empty(t_out * pix, cout, device='cuda', dtype=torch.bfloat16)
+    rows = _lib.load().sfvos_conv3d_stat_rows(ctypes.byref(d), None)
+    part = torch.empty(rows, 2, cout, device='cuda')
+    z = torch.zeros(1024, dtype=torch.uint8, device='cuda')
+    pp = None if pad_t > 0 else P(part)
+    ms = timeit(lambda: _lib.call('sfvos_conv3d', ctypes.byref(d), P(x), P(wp), None, P(y), pp, P(z), S()), reps)
+    fl = 2.0 * cin * cout * kt * taps * t_out * pix
+    print('conv  %-22s dbg=%s %8.3f ms %7.1f TF/s' % (name, os.environ.get('SFVOS_CONV_DEBUG', '0'), ms, fl / ms / 1e9),
+          flush=True)
+
+
+def wgrad(name, T, cin, cout, kt, taps, reps=5, shapes=SHAPES):
+    d, t_out = desc(T, cin, cout, kt, taps, 0, shapes)
+    pix = sum(h * w for h, w in shapes)
+    x = torch.randn(T * pix, cin, device='cuda').bfloat16()
+    dy = torch.randn(t_out * pix, cout, device='cuda').bfloat16()
+    gw = torch.empty(cout * cin * kt * taps, device='cuda')
+    ws = torch.empty(_lib.load().sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d)), dtype=torch.uint8, device='cuda')
+    z = torch.zeros(1024, dtype=torch.uint8, device='cuda')
+    ms = timeit(lambda: _lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(x), P(dy), P(gw), 0, P(ws), P(z), S()), reps)
+    fl = 2.0 * cin * cout * kt * taps * t_out * pix
+    print('wgrad %-22s       %8.3f ms %7.1f TF/s  (slab %.0f MB)' % (name, ms, fl / ms / 1e9, ws.numel() / 1e6), flush=True)
+
+
+which = sys.argv[1] if len(sys.argv) > 1 else 'all'
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+if which in ('all', 'f1'):
+    conv('f1 256->32 k11', 32, 256, 32, 11, 9, reps=reps)
+if which in ('all', 'wf1'):
+    wgrad('f1 256->32 k11', 32, 256, 32, 11, 9, reps=reps)
+if which == 'lat':
+    conv('dgrad l1 64->32 k20', 3, 64, 32, 20, 1, pad_t=19, reps=reps, acc=1)
+    conv('dgrad l2 64->32 k11', 2, 64, 32, 11, 1, pad_t=10, reps=reps, acc=1)
+if which == 'wide':
+    conv('s1 256->192 k2', 4, 256, 192, 2, 9, reps=reps)
+    conv('s2 256->192 k2', 3, 256, 192, 2, 9, reps=reps)
+    conv('s3 256->224 k2', 2, 256, 224, 2, 9, reps=reps)
+    conv('dgrad s2 192->256', 2, 192, 256, 2, 9, pad_t=1, reps=reps)
+    conv('dgrad s3 224->256', 1, 224, 256, 2, 9, pad_t=1, reps=reps)
+if which == 'wall':
+    wgrad('f1 256->32 k11', 32, 256, 32, 11, 9, reps=reps)
+    wgrad('s1 256->192 k2', 4, 256, 192, 2, 9, reps=reps)
+    wgrad('s2 256->192 k2', 3, 256, 192, 2, 9, reps=reps)
+    wgrad('s3 256->224 k2', 2, 256, 224, 2, 9, reps=reps)
+    wgrad('f2 32->32 k11', 22, 32, 32, 11, 9, reps=reps)
+    wgrad('f3 32->32 k12', 12, 32, 32, 12, 9, reps=reps)
+    wgrad('l1 32->64 k20', 22, 32, 64, 20, 1, reps=reps)
+    wgrad('l2 32->64 k11', 12, 32, 64, 11, 1, reps=reps)
+if which == 'f2':
+    conv('f2 32->32 k11', 22, 32, 32, 11, 9, reps=reps)
+if which == 'df2':
+    conv('dgrad f2 32->32 k11', 12, 32, 32, 11, 9, pad_t=10, reps=reps)
+if which == 'all':
+    conv('s1 256->192 k2', 4, 256, 192, 2, 9)
+    conv('s3 256->224 k2', 2, 256, 224, 2, 9)
+    conv('f2 32->32 k11', 22, 32, 32, 11, 9)
+    conv('l1 32->64 k20 1x1', 22, 32, 64, 20, 1)
+    conv('dgrad s2 192->256', 2, 192, 256, 2, 9, pad_t=1)
+    conv('dgrad l1 64->32 k20', 3, 64, 32, 20, 1, pad_t=19)
+    conv('dgrad f2 32->32 k11', 12, 32, 32, 11, 9, pad_t=10)
+    wgrad('s1 256->192 k2', 4, 256, 192, 2, 9)
+    wgrad('f2 32->32 k11', 22, 32, 32, 11, 9)
+    wgrad('l1 32->64 k20', 22, 32, 64, 20, 1)

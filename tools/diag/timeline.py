@@ -1,11 +1,12 @@
 import ctypes, os, sys, torch
 import numpy as np
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 NWG = 4096
 buf = torch.zeros(8 * 128 * 4 + 64 + 4 * NWG, dtype=torch.int64, device='cuda')
 os.environ['SFVOS_STAMP_PTR'] = hex(buf.data_ptr())
 sys.argv = ['mb', sys.argv[1] if len(sys.argv) > 1 else 'f1', '3']
-exec(open('/root/repo/scratch/mb_conv.py').read())
+exec(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'mb_conv.py')).read())
 torch.cuda.synchronize()
 tl = buf.cpu().numpy()[8 * 128 * 4 + 64:].reshape(NWG, 4)
 live = tl[:, 0] > 0
