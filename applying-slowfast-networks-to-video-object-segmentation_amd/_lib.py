@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SFVOS_LIB') or os.path.join(_HERE, 'csrc', 'libsfvos.so')  # SFVOS_LIB: A/B builds
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2
 MAX_LEVELS = 8
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -59,6 +59,8 @@ SIGNATURES = {
     'sfvos_check_device': (i32, []),
     'sfvos_frames_to_ndhwc': (i32, [vp, i64, i64, i64, i64, vp, i32, i32, i32, i32, i32, i32, vp]),
     'sfvos_frames_to_groups': (i32, [vp, i64, i64, i64, i64, vp, i32, i32, i32, i32, i32, i64, vp]),
+    'sfvos_frames_to_groups_fp8': (i32, [vp, i64, i64, i64, i64, vp, i32, i32, i32, i32, i64, f32, vp]),
+    'sfvos_pack_weights_fp8': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     'sfvos_ndhwc_to_planar': (i32, [vp, i32, vp, i64, i32, i32, vp]),
     'sfvos_planar_to_ndhwc': (i32, [vp, vp, i32, i64, i32, i32, vp]),
     'sfvos_ndhwc_to_frames': (i32, [vp, i32, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, vp]),

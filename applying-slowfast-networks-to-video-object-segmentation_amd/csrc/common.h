@@ -34,6 +34,14 @@ template <> struct Elt<SFVOS_BF16> {
   static __device__ __forceinline__ __bf16 from_f32(float v) { return (__bf16)v; }
 };
 
+template <> struct Elt<SFVOS_FP8> {   // OCP e4m3 bytes; conversions go through v_cvt_pk_fp8_f32 / v_cvt_f32_fp8
+  typedef unsigned char type;
+  static constexpr int CE = 16;
+};
+// element type a conv writes for a given operand type: fp8 operands -> bf16 results
+template <int DT> struct YOf { static constexpr int DTY = DT == SFVOS_FP8 ? SFVOS_BF16 : DT; };
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
 // One MFMA "step" consumes one 16-B chunk per lane of A and of B: lane half h (lane>>5)
 // holds chunk 2*step+h.  bf16: one 32x32x16; f32: four 32x32x2 (element e of both chunks
 // pairs k = {chunk(2s)*4+e, chunk(2s+1)*4+e}); the k-sum is the same set either way.

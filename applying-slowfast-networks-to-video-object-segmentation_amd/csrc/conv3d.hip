@@ -453,8 +453,13 @@ struct FsCfg {
 template <int DT, int TT, int RS, int CIN, bool M16>
 __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const ConvArgs::Part& pt) {
   typedef FsCfg<DT, TT, RS> C;
-  typedef typename Elt<DT>::type T;
-  constexpr int CE = Elt<DT>::CE, CK = 4 * CE, MT = C::MT, HM = C::HM;
+  // F8 (e4m3 operands, SFVOS_FP8): v_mfma_scale_f32_32x32x64_f8f6f4 -- one instruction consumes a pixel's whole
+  // 64-byte group (64 channels), the two wave halves split the wave's ROWS; results leave as bf16, de-quantised
+  // per output channel.  Everything about staging is shared: a 16-byte chunk just holds 16 channels.
+  constexpr bool F8 = DT == SFVOS_FP8;
+  constexpr int YDT = YOf<DT>::DTY;
+  typedef typename Elt<YDT>::type T;   // element type of y
+  constexpr int CE = Elt<DT>::CE, CEY = Elt<YDT>::CE, CK = 4 * CE, MT = C::MT, HM = C::HM;
   static_assert(!M16 || DT == SFVOS_BF16, "16x16x32 is the bf16 path");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ring = smem;
@@ -488,10 +493,10 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
   const long long xfs_bytes = a.lv.xfs[lvl] * a.x_pitch_bytes;  // bytes between consecutive frames of this level
   const char* xclip = a.x + (a.lv.xpos[lvl] + b * a.lv.xbs[lvl]) * a.x_pitch_bytes + a.t_offset * xfs_bytes;
 
-  f32x16 acc[M16 ? 1 : MT];   // 32x32 tiles: [row]
+  f32x16 acc[M16 ? 1 : (F8 ? HM : MT)];   // 32x32 tiles: [row]
   f32x4 acc16[M16 ? MT : 1][2];  // 16x16 tiles: [row][channel half]
 #pragma unroll
-  for (int i = 0; i < (M16 ? 1 : MT); ++i)
+  for (int i = 0; i < (M16 ? 1 : (F8 ? HM : MT)); ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 #pragma unroll
@@ -523,10 +528,13 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
     xo[it] = ok ? (unsigned)(((long long)h * W + w) * a.x_pitch_bytes + j * 16) : OOB;
   }
   int xsw[3];  // lane part of an A-fragment address for column shift dw (chunk 2kh+hh of pixel column r+dw)
+  int xsw8[2][3];  // F8: both halves of the 32-byte operand: chunks hh and 2+hh
 #pragma unroll
   for (int dw = 0; dw < 3; ++dw) {
     const int col = M16 ? kh * 16 + p16 + dw : r + dw;
     xsw[dw] = M16 ? (col * 4 + (g16 ^ (2 * ((col >> 2) & 1)))) * 16 : (col * 4 + ((2 * kh + hh) ^ ((col >> 2) & 3))) * 16;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) xsw8[st][dw] = ((r + dw) * 4 + ((2 * st + hh) ^ (((r + dw) >> 2) & 3))) * 16;
   }
 #pragma unroll
   for (int it = 0; it < NW; ++it) {
@@ -601,21 +609,41 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
   // in the first steps, so it has most of the stage to land; the scalar work for the next stage's descriptor
   // runs after the first MFMA group, in the shadow of the matrix pipe, not between barrier and first MFMA.
   auto compute = [&](int s, const Stage& cur, const Dma& d, Dma& dn, const Stage& nx) {
-    const char* wbl = wbase + (s & 1) * C::W_BYTES + (M16 ? g16 * C::BN + p16 : (2 * kh + hh) * C::BN + r) * 16;
-    const char* xfl = ring + wrap(cur.fslot + jf) * C::X_BYTES + rs * MT * C::HC * 64;
-    constexpr int ROWS = MT + 2, NA = 3 * ROWS, PDA = 3, NH = M16 ? 2 : 1;
-    static_assert(2 * NPIECE <= NA, "DMA pieces must fit the step count");
-    u32x4 av[PDA], bw[2][3][NH];
+    // F8: the wave owns rows [kh*HM, kh*HM+HM) of its row group; operand = chunks hh and 2+hh (32 bytes)
+    constexpr int MTW = F8 ? HM : MT;
+    const char* wbl = wbase + (s & 1) * C::W_BYTES +
+                      (M16 ? g16 * C::BN + p16 : F8 ? hh * C::BN + r : (2 * kh + hh) * C::BN + r) * 16;
+    const char* xfl = ring + wrap(cur.fslot + jf) * C::X_BYTES + (rs * MT + (F8 ? kh * HM : 0)) * C::HC * 64;
+    constexpr int ROWS = MTW + 2, NA = 3 * ROWS, PDA = 3, NH = M16 ? 2 : 1;
+    constexpr int PSTRIDE = 2 * NPIECE <= NA ? 2 : 1;  // copies go out in the first steps of the stage
+    static_assert(NPIECE <= NA, "DMA pieces must fit the step count");
+    u32x4 av[F8 ? 1 : PDA][1], bw[F8 ? 1 : 2][3][NH];
+    i32x8 av8[F8 ? PDA : 1], bw8[F8 ? 2 : 1][3];   // F8: 32-byte operands = chunks hh and 2+hh, one register octet
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    auto read8 = [&](const char* lo, const char* hi) {
+      const i32x4 l = __builtin_bit_cast(i32x4, lds_read16(lo)), h = __builtin_bit_cast(i32x4, lds_read16(hi));
+      return __builtin_shufflevector(l, h, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
     auto load_a = [&](int t) {
       const int dw = t / ROWS, rr = t - dw * ROWS;
-      av[t % PDA] = lds_read16(xfl + xsw[dw] + rr * C::HC * 64);
+      if constexpr (F8) {
+        av8[t % PDA] = read8(xfl + xsw8[0][dw] + rr * C::HC * 64, xfl + xsw8[1][dw] + rr * C::HC * 64);
+      } else {
+        av[t % PDA][0] = lds_read16(xfl + xsw[dw] + rr * C::HC * 64);
+      }
     };
     auto load_b = [&](int dw) {
 #pragma unroll
-      for (int dh = 0; dh < 3; ++dh)
+      for (int dh = 0; dh < 3; ++dh) {
+        if constexpr (F8) {
+          const char* wt = wbl + ((dh * 3 + dw) * 4 * C::BN) * 16;
+          bw8[dw & 1][dh] = read8(wt, wt + 2 * C::BN * 16);
+        } else {
 #pragma unroll
-        for (int nh = 0; nh < NH; ++nh)
-          bw[dw & 1][dh][nh] = lds_read16(wbl + ((dh * 3 + dw) * 4 * C::BN + nh * 16) * 16);
+          for (int nh = 0; nh < NH; ++nh)  // M16: nh = channel half
+            bw[dw & 1][dh][nh] = lds_read16(wbl + ((dh * 3 + dw) * 4 * C::BN + nh * 16) * 16);
+        }
+      }
     };
     load_b(0);
     load_a(0);
@@ -623,7 +651,7 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
 #pragma unroll
     for (int t = 0; t < NA; ++t) {
       const int dw = t / ROWS, rr = t - dw * ROWS;
-      if (t + PDA - 1 < NA && !(a.debug & 64)) {
+      if (t + PDA - 1 < NA) {
         if ((t + PDA - 1) % ROWS == 0) load_b((t + PDA - 1) / ROWS);
         load_a(t + PDA - 1);
       }
@@ -631,20 +659,24 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
 #pragma unroll
       for (int dh = 0; dh < 3; ++dh) {
         const int i = rr - dh;
-        if (i >= 0 && i < MT) {
+        if (i >= 0 && i < MTW) {
           if constexpr (M16) {
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh)
-              acc16[i][nh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[t % PDA]),
+              acc16[i][nh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av[t % PDA][0]),
                                                                     __builtin_bit_cast(bf16x8, bw[dw & 1][dh][nh]),
                                                                     acc16[i][nh], 0, 0, 0);
+          } else if constexpr (F8) {
+            // e4m3 x e4m3 (cbsz = blgp = 0), block scales 2^0 (E8M0 127): the real scales are applied in the epilogue
+            acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av8[t % PDA], bw8[dw & 1][dh], acc[i], 0, 0, 0, 127,
+                                                                     0, 127);
           } else {
-            Mma<DT>::run(acc[i], av[t % PDA], bw[dw & 1][dh][0]);
+            Mma<DT>::run(acc[i], av[t % PDA][0], bw[dw & 1][dh][0]);
           }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (t % 2 == 0 && t / 2 < NPIECE) piece(d, t / 2);
+      if (t % PSTRIDE == 0 && t / PSTRIDE < NPIECE) piece(d, t / PSTRIDE);
       if (t == 1) {
         if (s + 1 < S) prep_stage(dn, nx, s + 1);
         else dn.do_x = dn.do_w = false;
@@ -749,7 +781,10 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
   } else {
 // ---- K-half exchange: each partner hands the other the tiles it will not finish ----------------------
     f32x16 fin[HM];
-    {
+    if constexpr (F8) {   // the wave already holds complete sums of its HM rows
+#pragma unroll
+      for (int ii = 0; ii < HM; ++ii) fin[ii] = acc[ii];
+    } else {
       f32x4* mine = (f32x4*)(smem + wv * (HM * 4096)) + lane;
       const f32x4* theirs = (const f32x4*)(smem + (wv ^ 4) * (HM * 4096)) + lane;
       if (kh == 0) {
@@ -784,9 +819,10 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
   
     // ---- epilogue: rows kh*HM .. kh*HM+HM-1 of the wave's frame (as conv3d_kernel's, one channel tile) ----
     float* scr = (float*)smem + wv * (32 * 33);
-    constexpr int CPP = 32 / CE;
+    constexpr int CPP = 32 / CEY;
     if (r < a.c_out && to < pt.t_end) {  // c_out is a multiple of 32: always true for r; kept for symmetry
       const float bias = a.bias ? a.bias[r] : 0.f;
+      const float desc = F8 ? a.bias[a.c_out + r] : 1.f;  // e4m3: [2][c_out] = (bias, de-quantisation factor)
   #pragma unroll
       for (int ii = 0; ii < HM; ++ii) {
         const int h = h0 + rs * MT + kh * HM + ii;
@@ -794,29 +830,29 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
   #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int px = (e & 3) + 8 * (e >> 2) + 4 * hh;
-          const float v = fin[ii][e] + bias;
+          const float v = F8 ? fin[ii][e] * desc + bias : fin[ii][e] + bias;
           scr[px * 33 + r] = v;
           if (w0 + px < W) { s1 += v; s2 += v * v; }
         }
         T* yrow = yclip + (to * yfs + (long long)h * W + w0) * a.ld_y;
   #pragma unroll
         for (int it = 0; it < (32 * CPP) / 64; ++it) {
-          const int idx = it * 64 + lane, px = idx / CPP, ch = (idx % CPP) * CE;
-          float f[CE];
+          const int idx = it * 64 + lane, px = idx / CPP, ch = (idx % CPP) * CEY;
+          float f[CEY];
   #pragma unroll
-          for (int u = 0; u < CE; ++u) f[u] = scr[px * 33 + ch + u];
+          for (int u = 0; u < CEY; ++u) f[u] = scr[px * 33 + ch + u];
           if (w0 + px < W) {
             T* dst = yrow + (long long)px * a.ld_y + ch;
             if (a.accumulate) {
               const u32x4 old = *(const u32x4*)dst;
-              T oldv[CE];
+              T oldv[CEY];
               __builtin_memcpy(oldv, &old, 16);
   #pragma unroll
-              for (int u = 0; u < CE; ++u) f[u] += Elt<DT>::to_f32(oldv[u]);
+              for (int u = 0; u < CEY; ++u) f[u] += Elt<YDT>::to_f32(oldv[u]);
             }
-            T outv[CE];
+            T outv[CEY];
   #pragma unroll
-            for (int u = 0; u < CE; ++u) outv[u] = Elt<DT>::from_f32(f[u]);
+            for (int u = 0; u < CEY; ++u) outv[u] = Elt<YDT>::from_f32(f[u]);
             u32x4 o;
             __builtin_memcpy(&o, outv, 16);
             *(u32x4*)dst = o;
@@ -976,7 +1012,7 @@ static void split_frames_balanced(int t_out, long long units, ConvPlan* p) {
 
 static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
   SFVOS_REQUIRE(d != nullptr, "conv: null desc");
-  SFVOS_REQUIRE(d->dtype == SFVOS_F32 || d->dtype == SFVOS_BF16, "conv: bad dtype %d", d->dtype);
+  SFVOS_REQUIRE(d->dtype == SFVOS_F32 || d->dtype == SFVOS_BF16 || d->dtype == SFVOS_FP8, "conv: bad dtype %d", d->dtype);
   SFVOS_REQUIRE(d->taps == 9 || d->taps == 1, "conv: taps must be 9 or 1, got %d", d->taps);
   SFVOS_REQUIRE(d->c_in > 0 && d->c_in % 32 == 0 && d->c_out > 0 && d->c_out % 32 == 0,
                 "conv: channels must be positive multiples of 32 (c_in %d, c_out %d)", d->c_in, d->c_out);
@@ -985,12 +1021,16 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
   SFVOS_REQUIRE(d->t_offset >= 0 && d->t_alloc >= d->t_offset + d->t_in,
                 "conv: x window [t_offset %d, +t_in %d) exceeds t_alloc %d", d->t_offset, d->t_in, d->t_alloc);
   SFVOS_REQUIRE(d->pad_t >= 0 && d->pad_t < d->kt + 1, "conv: bad pad_t %d", d->pad_t);
-  const int ce = d->dtype == SFVOS_BF16 ? 8 : 4;
+  const int ce = d->dtype == SFVOS_BF16 ? 8 : d->dtype == SFVOS_FP8 ? 16 : 4;
+  if (d->dtype == SFVOS_FP8)
+    SFVOS_REQUIRE(d->taps == 9 && d->c_out <= 32 && d->c_in % 64 == 0 && d->accumulate == 0,
+                  "conv: e4m3 operands are implemented for the 3x3 layers with c_out <= 32 (c_in %% 64 == 0) only");
   SFVOS_REQUIRE(d->ld_y >= d->c_out, "conv: pitch smaller than channel count");
   SFVOS_REQUIRE(d->x_frame_stride >= 0 && d->y_frame_stride >= 0, "conv: negative frame stride");
   if (d->x_group_stride != 0) {
-    SFVOS_REQUIRE(d->dtype == SFVOS_BF16 && d->x_group_stride > 0 && d->x_group_stride % 8 == 0,
-                  "conv: the channel-group-major x layout is bf16 only, stride a positive multiple of 8 elements");
+    SFVOS_REQUIRE((d->dtype == SFVOS_BF16 || d->dtype == SFVOS_FP8) && d->x_group_stride > 0 &&
+                  d->x_group_stride % 16 == 0,
+                  "conv: the channel-group-major x layout needs bf16 / e4m3, stride a positive multiple of 16 elements");
   } else {
     SFVOS_REQUIRE(d->ld_x >= d->c_in, "conv: pitch smaller than channel count");
     SFVOS_REQUIRE(d->ld_x % ce == 0, "conv: ld_x %d must be a multiple of %d (16-byte chunks)", d->ld_x, ce);
@@ -1024,7 +1064,7 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
     const bool live = l < lv.n;
     const int H = live ? d->pyr.h[l] : 1, W = live ? d->pyr.w[l] : 1;
     SFVOS_REQUIRE(H >= 1 && W >= 1, "conv: level %d has bad extent %dx%d", l, H, W);
-    SFVOS_REQUIRE((long long)H * W * (d->x_group_stride ? 32 : d->ld_x) * (16 / ce) < (1ll << 31),
+    SFVOS_REQUIRE((long long)H * W * (d->x_group_stride ? 4 * ce : d->ld_x) * (16 / ce) < (1ll << 31),
                   "conv: level %d frame of %dx%d x pitch %d exceeds the 2 GiB per-frame offset range", l, H, W,
                   d->ld_x);
     lv.H[l] = H; lv.W[l] = W;
@@ -1128,7 +1168,8 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
   if (rc != SFVOS_OK) return rc;
   SFVOS_REQUIRE(x && w_packed && y && zeros, "conv: null pointer");
   SFVOS_REQUIRE(!(stat_part && d->accumulate), "conv: statistics are those of the conv result; not available with accumulate");
-  SFVOS_REQUIRE(d->ld_y % (d->dtype == SFVOS_BF16 ? 8 : 4) == 0, "conv: ld_y %d must be a multiple of a 16-byte chunk", d->ld_y);
+  SFVOS_REQUIRE(d->ld_y % (d->dtype == SFVOS_F32 ? 4 : 8) == 0, "conv: ld_y %d must be a multiple of a 16-byte chunk", d->ld_y);
+  SFVOS_REQUIRE(d->dtype != SFVOS_FP8 || bias != nullptr, "conv: e4m3 operands need the [2][c_out] (bias, descale) rows");
   SFVOS_REQUIRE(!(d->taps == 1 && p.family == 2), "conv: 1x1 conv with c_out > 64 has no kernel instance");
   if (!bias && !stat_part && d->taps == 1 && d->x_group_stride == 0 && d->x_frame_stride == 0 &&
       d->y_frame_stride == 0 && !getenv("SFVOS_NO_LATERAL_KERNEL")) {
@@ -1141,8 +1182,9 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
   a.batch = d->batch; a.t_in = d->t_in; a.t_alloc = d->t_alloc; a.t_offset = d->t_offset; a.t_out = p.t_out;
   a.c_in = d->c_in; a.c_out = d->c_out; a.kt = d->kt;
   a.pad_t = d->pad_t; a.ld_x = d->ld_x; a.ld_y = d->ld_y; a.accumulate = d->accumulate;
-  a.x_pitch_bytes = d->x_group_stride ? 64 : d->ld_x * (16 / (d->dtype == SFVOS_BF16 ? 8 : 4));
-  a.x_chunk_bytes = d->x_group_stride ? d->x_group_stride * 2 : 64;
+  const int es = d->dtype == SFVOS_BF16 ? 2 : d->dtype == SFVOS_FP8 ? 1 : 4;  // bytes per element of x
+  a.x_pitch_bytes = d->x_group_stride ? 64 : d->ld_x * es;
+  a.x_chunk_bytes = d->x_group_stride ? d->x_group_stride * es : 64;
   a.n_blocks = p.n_blocks; a.t_blocks_total = p.t_blocks;
   { const char* dbg = getenv("SFVOS_CONV_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
 #ifdef SFVOS_STAMP
@@ -1167,6 +1209,7 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
     SFVOS_REQUIRE(grid > 0 && grid < (1ll << 31), "conv: grid %lld out of range", grid);
     if (d->dtype == SFVOS_BF16)
       return d->c_in == 256 ? launch_fs<SFVOS_BF16, 256>(a, grid, s) : launch_fs<SFVOS_BF16>(a, grid, s);
+    if (d->dtype == SFVOS_FP8) return d->c_in == 256 ? launch_fs<SFVOS_FP8, 256>(a, grid, s) : launch_fs<SFVOS_FP8>(a, grid, s);
     return launch_fs<SFVOS_F32>(a, grid, s);
   }
   for (int c = 0; c < 3; ++c) a.part[c] = ConvArgs::Part{0, 0, 0, 0, 0};

@@ -17,7 +17,7 @@ struct PlanarView {
 // (one group), the channel-group-major input layout is gdiv = ld = 32, gstride = positions * 32
 template <int DT>
 __global__ __launch_bounds__(256) void to_ndhwc_kernel(const float* __restrict__ src, PlanarView v, char* dst, int ld,
-                                                       int gdiv, long long gstride) {
+                                                       int gdiv, long long gstride, float qscale = 1.f) {
   constexpr int CE = Elt<DT>::CE;
   __shared__ float tile[64][65];
   const int tid = threadIdx.x;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void to_ndhwc_kernel(const float* __restrict__
     if (p < HW && c0 + ch * CE < v.C) {
       float f[CE];
 #pragma unroll
-      for (int e = 0; e < CE; ++e) f[e] = tile[ch * CE + e][px];
+      for (int e = 0; e < CE; ++e) f[e] = DT == SFVOS_FP8 ? tile[ch * CE + e][px] * qscale : tile[ch * CE + e][px];
       const int c = c0 + ch * CE;
       *(u32x4*)(dst + ((c / gdiv) * gstride + ((long long)t * HW + p) * ld + c % gdiv) * (16 / CE)) = pack<DT>(f);
     }
@@ -92,6 +92,51 @@ __global__ __launch_bounds__(256) void mask_union_kernel(const float* __restrict
     unsigned char any = 0;
     for (int k = 0; k < n; ++k) any |= (unsigned char)(masks[(long long)k * hw + i] >= thr);
     out[i] = any;
+  }
+}
+
+// ---- e4m3 weight image (forward), per-output-channel scale ------------------------------------------
+// block n: max |w[n][...]| -> weight scale 448/max; writes the [2][c_out] (bias, descale) rows
+__global__ __launch_bounds__(256) void fp8_weight_scale_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                               long long per_n, int c_out, float act_scale,
+                                                               float* bias_descale, float* wscale) {
+  __shared__ float red[256];
+  const int n = blockIdx.x;
+  float m = 0.f;
+  for (long long i = threadIdx.x; i < per_n; i += 256) m = fmaxf(m, fabsf(w[(long long)n * per_n + i]));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + k]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float ws = red[0] > 0.f ? 448.f / red[0] : 1.f;
+    wscale[n] = ws;
+    bias_descale[n] = bias ? bias[n] : 0.f;
+    bias_descale[c_out + n] = 1.f / (act_scale * ws);
+  }
+}
+
+// packed[cc][dt][tap][j][n][16]: c = cc*64 + j*16 + e (as pack_weights_kernel with CE = 16)
+__global__ __launch_bounds__(256) void fp8_pack_weights_kernel(const float* __restrict__ w, const float* __restrict__ wscale,
+                                                               char* packed, int c_out, int c_in, int kt, int taps) {
+  const long long chunks = (long long)c_out * c_in * kt * taps / 16;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long long)gridDim.x * 256) {
+    long long k = i;
+    const int n = (int)(k % c_out); k /= c_out;
+    const int j = (int)(k % 4); k /= 4;
+    const int tap = (int)(k % taps); k /= taps;
+    const int dt = (int)(k % kt); k /= kt;
+    const int cc = (int)k;
+    const float ws = wscale[n];
+    float f[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int c = cc * 64 + j * 16 + e;
+      f[e] = w[(((long long)n * c_in + c) * kt + dt) * taps + tap] * ws;
+    }
+    *(u32x4*)(packed + i * 16) = pack<SFVOS_FP8>(f);
   }
 }
 
@@ -176,6 +221,35 @@ extern "C" int sfvos_frames_to_groups(const float* src, int64_t st, int64_t sc, 
   hipLaunchKernelGGL(to_ndhwc_kernel<SFVOS_BF16>, grid, dim3(256), 0, (hipStream_t)stream, src, v, (char*)dst, 32, 32,
                      (long long)group_stride);
   return check_launch("frames_to_groups");
+}
+
+extern "C" int sfvos_frames_to_groups_fp8(const float* src, int64_t st, int64_t sc, int64_t sh, int64_t sw, void* dst,
+                                          int T, int C, int H, int W, int64_t group_stride, float scale,
+                                          sfvos_stream_t stream) {
+  SFVOS_REQUIRE(src && dst && T > 0 && C > 0 && H > 0 && W > 0 && scale > 0.f, "frames_to_groups_fp8: bad argument");
+  SFVOS_REQUIRE(C % 64 == 0 && group_stride >= (int64_t)T * H * W * 64 && group_stride % 16 == 0,
+                "frames_to_groups_fp8: C must be a multiple of 64 and group_stride >= T*H*W*64");
+  PlanarView v{st, sc, sh, sw, T, C, H, W};
+  dim3 grid((unsigned)ceil_div64((int64_t)H * W, 64), (unsigned)ceil_div(C, 64), (unsigned)T);
+  hipLaunchKernelGGL(to_ndhwc_kernel<SFVOS_FP8>, grid, dim3(256), 0, (hipStream_t)stream, src, v, (char*)dst, 64, 64,
+                     (long long)group_stride, scale);
+  return check_launch("frames_to_groups_fp8");
+}
+
+extern "C" int sfvos_pack_weights_fp8(const float* w, const float* bias, void* packed, float* bias_descale, int c_out,
+                                      int c_in, int kt, int taps, float act_scale, sfvos_stream_t stream) {
+  SFVOS_REQUIRE(w && packed && bias_descale && c_out > 0 && c_in > 0 && kt > 0 && (taps == 9 || taps == 1) &&
+                act_scale > 0.f, "pack_weights_fp8: bad argument");
+  SFVOS_REQUIRE(c_in % 64 == 0 && c_out % 32 == 0, "pack_weights_fp8: c_in must be a multiple of 64, c_out of 32");
+  hipStream_t s = (hipStream_t)stream;
+  float* wscale = bias_descale + 2 * (long long)c_out;  // row 2 of the caller's buffer
+  const long long per_n = (long long)c_in * kt * taps;
+  hipLaunchKernelGGL(fp8_weight_scale_kernel, dim3(c_out), dim3(256), 0, s, w, bias, per_n, c_out, act_scale,
+                     bias_descale, wscale);
+  const long long chunks = (long long)c_out * per_n / 16;
+  hipLaunchKernelGGL(fp8_pack_weights_kernel, dim3(grid_for(chunks, 256)), dim3(256), 0, s, w, (const float*)wscale,
+                     (char*)packed, c_out, c_in, kt, taps);
+  return check_launch("pack_weights_fp8");
 }
 
 extern "C" int sfvos_planar_to_ndhwc(const float* src, void* dst, int dtype, int64_t M, int C, int ld,

@@ -42,6 +42,17 @@ template <> __device__ __forceinline__ u32x4 pack<SFVOS_BF16>(const float* f) {
   return v;
 }
 
+template <> __device__ __forceinline__ u32x4 pack<SFVOS_FP8>(const float* f) {  // 16 floats -> 16 e4m3 (saturating)
+  u32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * e], f[4 * e + 1], 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * e + 2], f[4 * e + 3], w, true);
+    v[e] = (unsigned)w;
+  }
+  return v;
+}
+
 // Deterministic column sums of part[rows][ncol]: block = 32 channels x RL row lanes, each lane sums
 // its strided rows (4 loads in flight), then lane 0 adds the RL lane sums in a fixed order.
 constexpr int RL = 32;
@@ -73,7 +84,7 @@ static inline unsigned grid_for(long long work_items, int per_block, unsigned ca
   return (unsigned)g;
 }
 
-#define DT_DISPATCH(dtype, CALL_F32, CALL_BF16)                    \
+#define DT_DISPATCH(dtype, CALL_F32, CALL_BF16)  /* f32 / bf16 only */                    \
   do {                                                             \
     if ((dtype) == SFVOS_F32) { CALL_F32; }                        \
     else if ((dtype) == SFVOS_BF16) { CALL_BF16; }                 \

@@ -39,7 +39,8 @@ extern "C" {
 
 typedef void* sfvos_stream_t; /* hipStream_t */
 
-enum { SFVOS_F32 = 0, SFVOS_BF16 = 1 };
+enum { SFVOS_F32 = 0, SFVOS_BF16 = 1,
+       SFVOS_FP8 = 2 /* OCP e4m3 operands; inference-only first step, see sfvos_conv_desc.dtype */ };
 
 enum {
   SFVOS_OK = 0,
@@ -113,10 +114,29 @@ int sfvos_pack_weights_fwd(const float* w, void* packed, int dtype, int c_out, i
 int sfvos_pack_weights_dgrad(const float* w, void* packed, int dtype, int c_out, int c_in, int kt, int taps,
                              sfvos_stream_t stream);
 
+/* e4m3 operands (SFVOS_FP8).  Frames fp32 -> 64-channel groups of e4m3: element (t,h,w,c) = sat(src * scale) at byte
+ * dst + (c/64)*group_stride + ((t*H+h)*W+w)*64 + c%64; C a multiple of 64. */
+int sfvos_frames_to_groups_fp8(const float* src, int64_t stride_t, int64_t stride_c, int64_t stride_h,
+                               int64_t stride_w, void* dst, int T, int C, int H, int W, int64_t group_stride,
+                               float scale, sfvos_stream_t stream);
+
+/* conv weight fp32 [c_out][c_in][kt][kh][kw] -> e4m3 forward image for sfvos_conv3d (dtype SFVOS_FP8), quantised per
+ * output channel: weight_scale[n] = 448 / max|w[n]|.  bias_descale: [3][c_out] floats: row 0 = bias (zeros when bias is
+ * NULL), row 1 = 1 / (act_scale * weight_scale[n]), row 2 = weight_scale[n] (sfvos_conv3d reads rows 0 and 1).
+ * c_in a multiple of 64. */
+int sfvos_pack_weights_fp8(const float* w, const float* bias, void* packed, float* bias_descale, int c_out, int c_in,
+                           int kt, int taps, float act_scale, sfvos_stream_t stream);
+
 /* ---- convolution (replaces aten::convolution at model.py:112,120,124,132,136,144,147) ---- */
 
 typedef struct sfvos_conv_desc {
-  int dtype;       /* SFVOS_F32: f32 storage, exact-f32 MFMA; SFVOS_BF16: bf16 storage, f32 accumulate */
+  int dtype;       /* SFVOS_F32: f32 storage, exact-f32 MFMA; SFVOS_BF16: bf16 storage, f32 accumulate;
+                    * SFVOS_FP8 (sfvos_conv3d only, 3x3 layers with c_out <= 32): x and the weight image are OCP e4m3
+                    * (x in 64-channel = 64-byte groups: x_group_stride > 0 counted in elements = bytes, or plain NDHWC
+                    * with ld_x a multiple of 64), products on v_mfma_scale_f32_32x32x64_f8f6f4 (2x the bf16 rate),
+                    * f32 accumulate, y stored as bf16; `bias` then points to [2][c_out] floats: row 0 the bias, row 1
+                    * the per-output-channel de-quantisation factor 1/(activation scale * weight scale[n])
+                    * (sfvos_pack_weights_fp8 writes both rows): y = acc * row1 + row0 */
   int batch;       /* clips B */
   int t_in;        /* input frames the conv sees */
   int t_alloc;     /* frames per clip the x BUFFER holds (>= t_offset + t_in): lets the slow pathway   */

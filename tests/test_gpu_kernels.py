@@ -423,3 +423,57 @@ def test_mask_union_matches_the_reference_numpy_loop(lib, n):
         total = np.logical_or(total, (m.numpy() >= 0.5)[0])
     got = union_mask(masks.cuda())
     assert got.dtype == torch.bool and np.array_equal(got.cpu().numpy(), total)
+
+
+@pytest.mark.parametrize('case', [(1, 6, [(12, 21), (5, 9)], 256, 32, 3), (2, 5, [(9, 17)], 64, 32, 2),
+                                  (1, 14, [(10, 33)], 128, 32, 11)])
+def test_conv3d_fp8_operands_match_a_dequantised_reference(lib, case):
+    """SFVOS_FP8 (first step of BASELINE config 5): e4m3 x (64-channel groups) and e4m3 weight image with
+    per-output-channel scales, f32 accumulate, bf16 result.  The reference convolves the SAME quantised values
+    (torch.float8_e4m3fn round trip) in fp32, so only summation order and the bf16 store differ: 1e-2."""
+    B, T, shapes, cin, cout, kt = case
+    g = torch.Generator().manual_seed(77)
+    w = torch.randn(cout, cin, kt, 3, 3, generator=g) / np.sqrt(cin * kt * 9)
+    w[3] *= 7.0                                                     # channels with different ranges
+    bias = torch.randn(cout, generator=g) * 0.1
+    xs = [torch.randn(B, cin, T, H, W, generator=g) for (H, W) in shapes]
+    act_scale = 32.0
+    M = sum(B * T * H * W for H, W in shapes)
+    x_gr = torch.zeros((cin // 64, M, 64), dtype=torch.uint8, device='cuda')
+    off = 0
+    for x in xs:
+        H, W = x.shape[3], x.shape[4]
+        xc = x.cuda()
+        for b in range(B):
+            s = xc[b]
+            lib.call('sfvos_frames_to_groups_fp8', P(s), s.stride(1), s.stride(0), s.stride(2), s.stride(3),
+                     P(x_gr, (off + b * T * H * W) * 64), T, cin, H, W, M * 64, act_scale, S())
+        off += B * T * H * W
+    wp = torch.empty(w.numel(), dtype=torch.uint8, device='cuda')
+    bd = torch.empty((3, cout), dtype=torch.float32, device='cuda')
+    w_dev, bias_dev = w.cuda(), bias.cuda()   # keep both alive: two temporaries would share one freed block
+    lib.call('sfvos_pack_weights_fp8', P(w_dev), P(bias_dev), P(wp), P(bd), cout, cin, kt, 9, act_scale, S())
+    d, t_out = make_desc(lib, 'bf16', B, T, shapes, cin, cout, kt, 9, 0, 64, cout)
+    d.dtype = lib.FP8
+    d.x_group_stride = M * 64
+    Mo = sum(B * t_out * H * W for H, W in shapes)
+    y = torch.zeros((Mo, cout), dtype=torch.bfloat16, device='cuda')
+    rows = lib.load().sfvos_conv3d_stat_rows(ctypes.byref(d), None)
+    part = torch.zeros((rows, 2, cout), dtype=torch.float32, device='cuda')
+    zeros = torch.zeros(1024, dtype=torch.uint8, device='cuda')
+    lib.call('sfvos_conv3d', ctypes.byref(d), P(x_gr), P(wp), P(bd), P(y), P(part), P(zeros), S())
+    torch.cuda.synchronize()
+    # reference on the same quantised operands
+    f8 = torch.float8_e4m3fn
+    ws = 448.0 / w.abs().amax(dim=(1, 2, 3, 4))
+    wq = (w * ws[:, None, None, None, None]).to(f8).float() / ws[:, None, None, None, None]
+    assert torch.allclose(bd[2].cpu(), ws, rtol=1e-6) and torch.allclose(bd[1].cpu(), 1.0 / (act_scale * ws), rtol=1e-6)
+    refs = [F.conv3d((x * act_scale).to(f8).float() / act_scale, wq, bias, padding=(0, 1, 1)) for x in xs]
+    got = from_pyr(y, B, cout, t_out, shapes)
+    for a, r in zip(got, refs):
+        assert relmax(a, r) < 1e-2
+    # and the quantisation error itself against the unquantised conv, for the record (not a gate): ~3-5 %
+    full = [F.conv3d(x, w, bias, padding=(0, 1, 1)) for x in xs]
+    err = max(float((a.double() - f.double()).norm() / f.double().norm()) for a, f in zip(got, full))
+    print('e4m3 conv rel-L2 error vs fp32 operands: %.3f' % err)
+    assert err < 0.1

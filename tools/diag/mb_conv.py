@@ -49,6 +49,28 @@ def conv(name, T, cin, cout, kt, taps, pad_t=0, reps=5, shapes=SHAPES, acc=0):
           flush=True)
 
 
+def conv_fp8(name, T, cin, cout, kt, reps=5, shapes=SHAPES):
+    """e4m3 operands, x in 64-channel groups (fast_conv1 forward shape)"""
+    d, t_out = desc(T, cin, cout, kt, 9, 0, shapes)
+    d.dtype = _lib.FP8
+    pix = sum(h * w for h, w in shapes)
+    M = T * pix
+    d.ld_x, d.x_group_stride = 64, M * 64
+    x = torch.randint(0, 256, (cin // 64, M, 64), device='cuda', dtype=torch.uint8)
+    x = torch.where((x & 0x7f) > 0x7d, x & 0xf0, x)            # no NaN encodings
+    w = torch.randn(cout, cin, kt, 3, 3, device='cuda') * 0.02
+    wp = torch.empty(w.numel(), dtype=torch.uint8, device='cuda')
+    bd = torch.empty((3, cout), device='cuda')
+    _lib.call('sfvos_pack_weights_fp8', P(w), None, P(wp), P(bd), cout, cin, kt, 9, 32.0, S())
+    y = torch.empty(t_out * pix, cout, device='cuda', dtype=torch.bfloat16)
+    rows = _lib.load().sfvos_conv3d_stat_rows(ctypes.byref(d), None)
+    part = torch.empty(rows, 2, cout, device='cuda')
+    z = torch.zeros(1024, dtype=torch.uint8, device='cuda')
+    ms = timeit(lambda: _lib.call('sfvos_conv3d', ctypes.byref(d), P(x), P(wp), P(bd), P(y), P(part), P(z), S()), reps)
+    fl = 2.0 * cin * cout * kt * 9 * t_out * pix
+    print('conv  %-22s fp8     %8.3f ms %7.1f TF/s' % (name, ms, fl / ms / 1e9), flush=True)
+
+
 def wgrad(name, T, cin, cout, kt, taps, reps=5, shapes=SHAPES):
     d, t_out = desc(T, cin, cout, kt, taps, 0, shapes)
     pix = sum(h * w for h, w in shapes)
@@ -65,6 +87,9 @@ def wgrad(name, T, cin, cout, kt, taps, reps=5, shapes=SHAPES):
 which = sys.argv[1] if len(sys.argv) > 1 else 'all'
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 if which in ('all', 'f1'):
+    conv('f1 256->32 k11', 32, 256, 32, 11, 9, reps=reps)
+if which == 'f1f8':
+    conv_fp8('f1 256->32 k11', 32, 256, 32, 11, reps=reps)
     conv('f1 256->32 k11', 32, 256, 32, 11, 9, reps=reps)
 if which in ('all', 'wf1'):
     wgrad('f1 256->32 k11', 32, 256, 32, 11, 9, reps=reps)
