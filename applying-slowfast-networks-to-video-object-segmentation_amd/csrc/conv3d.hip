@@ -36,6 +36,14 @@
 #define SFVOS_STAMP_AT(idx)
 #endif
 
+// Timing-only switches (SFVOS_CONV_DEBUG bits; results are WRONG with them) exist only in diagnostic builds
+// (-DSFVOS_DIAG): in the shipped library every test folds to a constant, so no branch, no extra live range.
+#ifdef SFVOS_DIAG
+#define SFVOS_DBG(bit) ((a.debug & (bit)) != 0)
+#else
+#define SFVOS_DBG(bit) false
+#endif
+
 namespace sfvos {
 
 struct ConvLevels {
@@ -287,7 +295,7 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
   // The second-dispatched half of the workgroup loses VALU/LDS issue arbitration to its older SIMD
   // partner on every stage (stamps: it finishes its MFMAs ~30 % later and the older half then idles
   // at the barrier); one static priority raise evens them out.
-  if (C::NWAVES == 8 && wv >= 4 && !(a.debug & 32)) __builtin_amdgcn_s_setprio(1);
+  if (C::NWAVES == 8 && wv >= 4 && !SFVOS_DBG(32)) __builtin_amdgcn_s_setprio(1);
   for (int cc = 0; cc < ncc && S > 0; ++cc) {
     // chunk prologue: refill the ring with the first TT frames of this chunk.  All waves must have
     // finished the previous chunk's last stage before its live slots are overwritten.
@@ -307,20 +315,20 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
       for (int tg = 0; tg < C::NTG; ++tg, ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         SFVOS_STAMP_AT(3)
-        if (!(a.debug & 16)) __syncthreads();  // stage s operands landed; everyone is done with stage s-1
+        if (!SFVOS_DBG(16)) __syncthreads();  // stage s operands landed; everyone is done with stage s-1
         SFVOS_STAMP_AT(0)
         Dma d; d.do_x = d.do_w = false;
-        if (!(a.debug & 2)) {
+        if (!SFVOS_DBG(2)) {
           // next frame goes into the slot freed by frame dt-1; next stage's weights into the other buffer
-          if (tg == 0 && dt < dt_hi && !(a.debug & 4)) prep_frame(d, cc, dt + TT, wrap(fslot + TT));
-          if (s + 1 < S && !(a.debug & 8)) {
+          if (tg == 0 && dt < dt_hi && !SFVOS_DBG(4)) prep_frame(d, cc, dt + TT, wrap(fslot + TT));
+          if (s + 1 < S && !SFVOS_DBG(8)) {
             int ntg = tg + 1, ndt = dt, ncc2 = cc;
             if (ntg == C::NTG) { ntg = 0; if (++ndt > dt_hi) { ndt = dt_lo; ++ncc2; } }
             prep_w(d, ncc2, ndt, ntg, s + 1);
           }
         }
         SFVOS_STAMP_AT(1)
-        if (!(a.debug & 1)) compute(tg, s, fslot, d);
+        if (!SFVOS_DBG(1)) compute(tg, s, fslot, d);
         else issue_all(d);
         SFVOS_STAMP_AT(2)
       }
@@ -597,7 +605,7 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
   // the copy that runs DURING stage x (index s): the next ring frame of this chunk and the next stage's weights
   auto prep_stage = [&](Dma& d, const Stage& x, int s) {
     d.do_x = d.do_w = false;
-    if (a.debug & 2) return;
+    if (SFVOS_DBG(2)) return;
     if (x.dt < dt_hi) prep_frame(d, x.cc, x.dt + TT, wrap(x.fslot + TT));
     if (s + 1 < S) {
       const Stage n = next_of(x);
@@ -714,12 +722,12 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SFVOS_STAMP_AT(3)
-    if (!(a.debug & 16)) __syncthreads();
+    if (!SFVOS_DBG(16)) __syncthreads();
     SFVOS_STAMP_AT(0)
     const Stage nx = next_of(cur);
     Dma dn;
     SFVOS_STAMP_AT(1)
-    if (!(a.debug & 1)) compute(s, cur, d, dn, nx);
+    if (!SFVOS_DBG(1)) compute(s, cur, d, dn, nx);
     else { issue_all(d); if (s + 1 < S) prep_stage(dn, nx, s + 1); else dn.do_x = dn.do_w = false; }
     SFVOS_STAMP_AT(2)
     d = dn;
