@@ -21,7 +21,9 @@ from torch import nn
 from . import _lib
 from .plan import SlowFastPlan
 
-_DT = {'fp32': (_lib.F32, torch.float32), 'bf16': (_lib.BF16, torch.bfloat16)}
+_DT = {'fp32': (_lib.F32, torch.float32), 'bf16': (_lib.BF16, torch.bfloat16),
+       # 'fp8': inference only; fast_conv1 (72 % of the forward FLOPs) runs on e4m3 operands, everything else as bf16
+       'fp8': (_lib.BF16, torch.bfloat16)}
 # per-level coefficient rows of a BN layer: mean, rstd, scale, shift, var_unbiased, A, B, K
 _CF_ROWS = 8
 _MEAN, _RSTD, _SCALE, _SHIFT, _VARU, _CA, _CB, _CK = range(8)
@@ -175,7 +177,8 @@ class SlowFastLayers(nn.Module):
             self.add_module(name, mod)
         self.precision = precision or os.environ.get('SFVOS_PRECISION', 'fp32')
         if self.precision not in _DT:
-            raise ValueError("precision must be 'fp32' or 'bf16', got %r" % (self.precision,))
+            raise ValueError("precision must be 'fp32', 'bf16' or 'fp8', got %r" % (self.precision,))
+        self.fp8_input_scale = 32.0   # e4m3 activation scale of the input clip (|x| * scale must stay below 448)
         self._packs = {}     # (conv name, kind, dtype) -> ((param version, data_ptr, epoch), packed tensor)
         self._zeros = None
         self._timer = None
@@ -222,6 +225,26 @@ class SlowFastLayers(nn.Module):
         _lib.call(fn, _ptr(wc), _ptr(packed), dt_id, layer.c_out, layer.c_in, layer.kt, layer.taps, _stream())
         self._packs[key] = (tag, packed)
         return packed
+
+    def _packed_fp8(self, layer):
+        """(e4m3 weight image, [3][c_out] (bias, descale, weight scale) rows) of a 3x3 layer, cached like _packed."""
+        conv = getattr(self, layer.conv)
+        w = conv.weight
+        key = (layer.conv, 'fwd8', float(self.fp8_input_scale))
+        hit = self._packs.get(key)
+        tag = (w._version, w.data_ptr(), _lib.weight_epoch(), None if conv.bias is None else conv.bias._version)
+        if hit is not None and hit[0] == tag:
+            return hit[1]
+        packed = torch.empty(w.numel(), dtype=torch.uint8, device=w.device)
+        bd = torch.empty((3, layer.c_out), dtype=torch.float32, device=w.device)
+        wc = w.detach()
+        if wc.dtype != torch.float32 or not wc.is_contiguous():
+            wc = wc.float().contiguous()
+        bc = None if conv.bias is None else conv.bias.detach().float().contiguous()
+        _lib.call('sfvos_pack_weights_fp8', _ptr(wc), _ptr(bc) if bc is not None else None, _ptr(packed), _ptr(bd),
+                  layer.c_out, layer.c_in, layer.kt, layer.taps, float(self.fp8_input_scale), _stream())
+        self._packs[key] = (tag, (packed, bd))
+        return packed, bd
 
     def _desc(self, layer, B, pyr, dt_id, ld_x, ld_y, t_alloc=None, t_offset=0, dgrad=False, accumulate=0):
         """ld_x: pitch of x in elements, or the x tensor itself ([M, ld] ndhwc / [G, M, 32] grouped)."""
@@ -272,11 +295,15 @@ class SlowFastLayers(nn.Module):
         clip aliases frames [slow_offset, slow_offset+sp) of the fast clip).
         Returns (list of merged [B,256,H,W] fp32 per level, state or None)."""
         plan = self.plan
-        dt_name = self.precision
+        fp8 = self.precision == 'fp8'
+        dt_name = 'bf16' if fp8 else self.precision
         dt_id, tdt = _DT[dt_name]
         dev = xf0.device
         zeros = self._zero_page(dev)
         L = len(shapes)
+        if fp8 and (self.training or keep):
+            raise RuntimeError("precision='fp8' is inference-only (eval mode, no autograd state): the e4m3 path has "
+                               "no backward in this build")
         pix = sum(h * w for h, w in shapes)
         pyr = _lib.make_pyramid(shapes)
         bufs = {'xf0': xf0}
@@ -297,10 +324,17 @@ class SlowFastLayers(nn.Module):
                     bufs[name] = torch.empty((B * b.frames * pix, b.channels), dtype=tdt, device=dev)
             sname, t_alloc, t_off = self._src_window(l, slow_offset)
             src = bufs[sname]
-            d = self._desc(l, B, pyr, dt_id, src, l.c_out, t_alloc, t_off)
             lv = _lib.make_levels(shapes, B, l.t_out)
-            w = dict(d=d, lv=lv, src=src, wp=self._packed(l, 'fwd', dt_name),
-                     cf=torch.empty((L, _CF_ROWS, l.c_out), dtype=torch.float32, device=dev))
+            if fp8 and l.name == 'f1':   # e4m3 operands: x = [C/64][M][64] bytes, (bias, descale) rows as `bias`
+                d = self._desc(l, B, pyr, _lib.FP8, 64, l.c_out)
+                d.x_group_stride = src.shape[1] * 64
+                wp, bd = self._packed_fp8(l)
+                w = dict(d=d, lv=lv, src=src, wp=wp, bias8=bd,
+                         cf=torch.empty((L, _CF_ROWS, l.c_out), dtype=torch.float32, device=dev))
+            else:
+                d = self._desc(l, B, pyr, dt_id, src, l.c_out, t_alloc, t_off)
+                w = dict(d=d, lv=lv, src=src, wp=self._packed(l, 'fwd', dt_name),
+                         cf=torch.empty((L, _CF_ROWS, l.c_out), dtype=torch.float32, device=dev))
             if train:
                 if min(lv.m[i] for i in range(L)) <= 1:
                     raise ValueError('Expected more than 1 value per channel when training, got input size %s'
@@ -326,6 +360,8 @@ class SlowFastLayers(nn.Module):
             raw, dst = bufs[l.raw], bufs[l.dst]
             cs = _CF_ROWS * l.c_out
             bias = _ptr(conv.bias.detach()) if conv.bias is not None else None
+            if 'bias8' in w:
+                bias = _ptr(w['bias8'])
             stream = side if (side is not None and self._on_side(l)) else main
             with torch.cuda.stream(stream):
                 st = _stream()
@@ -570,6 +606,26 @@ class SlowFastLayers(nn.Module):
             off += B * frames * H * W
         return flat
 
+    def _to_pyramid_fp8(self, tensors, frames):
+        """list over levels of [B,C,T,H,W] fp32 -> e4m3 clip [C/64][M][64] (sfvos_frames_to_groups_fp8)."""
+        B, C = tensors[0].shape[0], tensors[0].shape[1]
+        if C % 64 != 0:
+            raise RuntimeError("precision='fp8' needs an input channel count that is a multiple of 64")
+        pix = sum(t.shape[3] * t.shape[4] for t in tensors)
+        M = B * frames * pix
+        flat = torch.empty((C // 64, M, 64), dtype=torch.uint8, device=tensors[0].device)
+        st = _stream()
+        off = 0
+        for t in tensors:
+            s = t if t.dtype == torch.float32 else t.float()
+            H, W = s.shape[3], s.shape[4]
+            for b in range(B):
+                _lib.call('sfvos_frames_to_groups_fp8', _ptr(s[b]), s.stride(2), s.stride(1), s.stride(3), s.stride(4),
+                          _ptr(flat, (off + b * frames * H * W) * 64), frames, C, H, W, M * 64,
+                          float(self.fp8_input_scale), st)
+            off += B * frames * H * W
+        return flat
+
     def _slow_alias_offset(self, slow_list, fast_list):
         """k if every slow[l] is exactly frames [k, k+sp) of fast[l] (same storage and strides -- what
         SegmentationModel passes, model.py:336-338), else None."""
@@ -630,6 +686,9 @@ class SlowFastLayers(nn.Module):
         The slow pathway reads frames [slow_offset, slow_offset+sp) of the same clip; default = the
         centre frames, as SegmentationModel._slice_features takes them (model.py:242-248,322,337)."""
         self._check_ready(clip.data)
+        if self.precision == 'fp8':
+            raise RuntimeError("precision='fp8' takes frames (temporally_enhance_features); there is no packed e4m3 "
+                               "clip format in this build")
         plan = self.plan
         _, tdt = _DT[self.precision]
         if clip.frames != plan.fp or clip.channels != plan.input_size or clip.data.dtype != tdt \
@@ -663,8 +722,14 @@ class _SlowFastPyramidFn(torch.autograd.Function):
             B = fast_list[0].shape[0]
             shapes = [tuple(f.shape[3:]) for f in fast_list]
             slow_offset = module._slow_alias_offset(slow_list, fast_list)
-            xf0 = module._to_pyramid(fast_list, module.plan.fp, dt_id, tdt)
-            xs0 = None if slow_offset is not None else module._to_pyramid(slow_list, module.plan.sp, dt_id, tdt)
+            if module.precision == 'fp8':
+                # the fast clip as e4m3 (read by fast_conv1 only); the few slow frames separately as bf16
+                xf0 = module._to_pyramid_fp8(fast_list, module.plan.fp)
+                xs0 = module._to_pyramid(slow_list, module.plan.sp, dt_id, tdt)
+                slow_offset = None
+            else:
+                xf0 = module._to_pyramid(fast_list, module.plan.fp, dt_id, tdt)
+                xs0 = None if slow_offset is not None else module._to_pyramid(slow_list, module.plan.sp, dt_id, tdt)
             ctx.in_meta = [(t.shape, t.dtype) for t in tensors[:n_in]]
         else:
             n_in = 1

@@ -69,7 +69,7 @@ class SlowFastStream(object):
         _lib.load()
         self.chunk = G = int(chunk)
         self.dev = dev = w.device
-        self.dt_name = module.precision
+        self.dt_name = 'bf16' if module.precision == 'fp8' else module.precision   # the stream runs fp8 modules as bf16
         self.dt_id, self.tdt = _DT[self.dt_name]
         self.FS = FS = sum(h * w_ for h, w_ in self.shapes)   # positions of one whole-pyramid frame (B = 1)
         self.lpos = []

@@ -71,6 +71,26 @@ def main():
             model.enhance_packed(clip)
         torch.cuda.synchronize()
         dt_full = (time.time() - t0) / reps
+        # the whole window from fp32 frames (the reference's calling convention), bf16 vs the e4m3 fast_conv1 path
+        win = {}
+        frames_fast = [OrderedDict((k, torch.randn((args.fp, 256, h, w), generator=gen, device=dev)) for k, (h, w) in pyr)]
+        c = args.fp // 2
+        frames_slow = [OrderedDict((k, v[c - args.sp // 2: c + (args.sp + 1) // 2]) for k, v in frames_fast[0].items())]
+        for prec in ('bf16', 'fp8'):
+            m2 = SlowFastLayers(256, dev, args.sp, args.fp, precision=prec).to(dev).eval()
+            m2.load_state_dict(model.state_dict())
+            for _ in range(2):
+                m2.temporally_enhance_features(frames_slow, frames_fast)
+            timer = m2.enable_kernel_timer()
+            timer.reset()
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for _ in range(5):
+                m2.temporally_enhance_features(frames_slow, frames_fast)
+            torch.cuda.synchronize()
+            win[prec] = {'ms': round((time.time() - t0) / 5 * 1e3, 3),
+                         'fast_conv1_ms': round(timer.summary()['conv_fwd/f1'][1], 3)}
+            del m2
     P = sum(h * w for h, w in shapes)
     plan = model.plan
     flops_stream = sum(2.0 * l.c_in * l.c_out * l.kt * l.taps * P for l in plan.layers)   # one output frame per layer
@@ -83,6 +103,7 @@ def main():
         'recompute_window_per_frame': {'value': round(1.0 / dt_full, 2), 'ms_per_frame': round(1e3 * dt_full, 3),
                                        'gflop_per_frame': round(plan.forward_flops(P) / 1e9, 1),
                                        'note': 'window already channels-last on the GPU; the reference also restacks it'},
+        'window_from_fp32_frames': win,
         'speedup': round(dt_full / dt_stream, 2), 'speedup_chunked': round(dt_full / res[args.chunk], 2), 'dtype': args.precision, 'data': 'synthetic',
         'config': {'workload': 'SlowFastLayers (sp=%d, fp=%d) eval forward per video frame, 5 FPN levels (P=%d)'
                                % (args.sp, args.fp, P)}}))
