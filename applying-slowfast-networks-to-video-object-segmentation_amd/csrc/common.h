@@ -67,6 +67,36 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 
 __device__ __forceinline__ u32x4 lds_read16(const void* p) { return *(const u32x4*)p; }
 
+// LDS-DMA through a buffer descriptor, as one asm statement: buffer_load_dwordx4 ... offen lds.
+// Why not __builtin_amdgcn_raw_ptr_buffer_load_lds: hipcc tracks that builtin as an LDS write and, when it cannot
+// prove that the destination does not alias a following LDS read (dynamic ring slots), puts `s_waitcnt vmcnt(0)`
+// right behind the copy -- a full memory round trip inside the MFMA loop.  The copies here are ordered by hand
+// (one `s_waitcnt vmcnt(0)` + barrier per stage before anything reads what they wrote), so the statement is opaque
+// to the compiler on purpose.  M0 (the LDS destination base) is saved and restored inside the statement.
+//   base/records: descriptor of the source (wave-uniform); voff: this lane's byte offset, >= records reads zeros;
+//   lds_offset: wave-uniform byte offset inside the workgroup's LDS allocation (kernels here have dynamic LDS only, so
+//   `ptr - smem` is the LDS address), lane i lands at +16 i.
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+__device__ __forceinline__ void lds_dma16(const void* base, int records, unsigned voff, unsigned lds_offset) {
+  const unsigned long long b = (unsigned long long)base;
+  i32x4 rs;
+  rs[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  rs[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xffffu));   // stride 0
+  rs[2] = __builtin_amdgcn_readfirstlane(records);
+  rs[3] = 0x00020000;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_offset);
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(dst), "v"(voff), "s"(rs)
+      : "memory");
+}
+
 // ---- host side -------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);

@@ -191,14 +191,12 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     if (p * 8 + wv < C::XWP) {
       // wave-piece -> its 32-channel tile -> (grouped layout) that tile's channel group
       const long long goff = a.x_group_bytes * ((c_base >> 5) + (p * 8 + wv) / (C::XT_SLOTS / 64));
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(c.src + goff), 0, c.rec, 0x00020000);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (SFVOS_LDS void*)(c.dst + p * 8192), 16, xo[p], 0, 0, 0);
+      lds_dma16(c.src + goff, c.rec, xo[p], (unsigned)(c.dst - smem) + p * 8192);
     }
   };
   auto dy_piece = [&](const Copy& c, int p) {
     if (p * 8 + wv < C::DWP) {
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)c.src, 0, c.rec, 0x00020000);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (SFVOS_LDS void*)(c.dst + p * 8192), 16, dyo[p], 0, 0, 0);
+      lds_dma16(c.src, c.rec, dyo[p], (unsigned)(c.dst - smem) + p * 8192);
     }
   };
   auto load_x_now = [&]() {
