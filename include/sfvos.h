@@ -168,7 +168,8 @@ int sfvos_conv3d_stat_rows(const sfvos_conv_desc* d, int* rows_per_level);
 /* y (=|+=) bias + sum_{dt,dh,dw,c} x[l][b][t_offset+t+dt-pad_t][h+dh-1][w+dw-1][c] * W over every level.
  * x: pyramid buffer with t_alloc frames; y: pyramid buffer with t_out = t_in + 2*pad_t - kt + 1 frames.
  * bias may be NULL.  stat_part may be NULL; otherwise it receives per-tile partial (sum, sum of
- * squares) of the values written.  `zeros`: caller-provided zero-filled device buffer >= 256 B. */
+ * squares) of the values written.  `zeros`: caller-provided zero-filled device buffer >= 256 B (must be non-NULL;
+ * kept for ABI stability -- the kernels now zero-fill padding through the buffer descriptors' range check). */
 int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
                  float* stat_part, const void* zeros, sfvos_stream_t stream);
 
