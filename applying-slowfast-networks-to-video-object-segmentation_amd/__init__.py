@@ -7,8 +7,9 @@ one-process-per-GPU data parallelism)."""
 from .plan import SlowFastPlan, calc_fuse_kernel_size, calc_kernel_sizes, davis_pyramid  # noqa: F401
 from .module import PackedClip, SlowFastLayers, union_mask  # noqa: F401
 from .optim import FusedSGD  # noqa: F401
+from .losses import MSEProxyLoss  # noqa: F401
 from .stream import SlowFastStream  # noqa: F401
 from .parallel import GradBucket, init_distributed  # noqa: F401
 
 __all__ = ['SlowFastLayers', 'PackedClip', 'SlowFastPlan', 'FusedSGD', 'GradBucket', 'init_distributed',
-           'calc_kernel_sizes', 'calc_fuse_kernel_size', 'davis_pyramid', 'union_mask', 'SlowFastStream']
+           'MSEProxyLoss', 'calc_kernel_sizes', 'calc_fuse_kernel_size', 'davis_pyramid', 'union_mask', 'SlowFastStream']

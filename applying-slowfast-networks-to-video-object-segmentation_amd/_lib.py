@@ -25,10 +25,22 @@ class Levels(C.Structure):
 
 
 class ConvDesc(C.Structure):
-    """Mirror of sfvos_conv_desc (include/sfvos.h)."""
-    _fields_ = [('dtype', i32), ('batch', i32), ('t_in', i32), ('t_alloc', i32), ('t_offset', i32), ('c_in', i32),
+    """Mirror of sfvos_conv_desc (include/sfvos.h).  struct_size is filled in by the constructor; the library
+    rejects a descriptor whose size differs from its own struct (stale binding)."""
+    _fields_ = [('struct_size', i32), ('dtype', i32), ('batch', i32), ('t_in', i32), ('t_alloc', i32), ('t_offset', i32), ('c_in', i32),
                 ('c_out', i32), ('kt', i32), ('taps', i32), ('pad_t', i32), ('ld_x', i32), ('ld_y', i32),
                 ('accumulate', i32), ('pyr', Pyramid), ('x_group_stride', i64), ('x_frame_stride', i64), ('y_frame_stride', i64)]
+
+
+    def __init__(self, *args, **kw):
+        super(ConvDesc, self).__init__(*args, **kw)
+        self.struct_size = C.sizeof(ConvDesc)
+
+
+class MseTable(C.Structure):
+    """Mirror of sfvos_mse_table."""
+    _fields_ = [('n', i32), ('out', vp * MAX_LEVELS), ('target', vp * MAX_LEVELS), ('grad', vp * MAX_LEVELS),
+                ('numel', i64 * MAX_LEVELS)]
 
 
 def make_pyramid(shapes):
@@ -50,16 +62,18 @@ def make_levels(shapes, batch, frames):
     return lv
 
 
-PD, PL = C.POINTER(ConvDesc), C.POINTER(Levels)
+PD, PL, PM = C.POINTER(ConvDesc), C.POINTER(Levels), C.POINTER(MseTable)
 
 # name -> (restype, argtypes); every symbol include/sfvos.h declares
 SIGNATURES = {
     'sfvos_version': (i32, []),
+    'sfvos_abi_sizes': (i32, [C.POINTER(i32), i32]),
     'sfvos_last_error': (C.c_char_p, []),
     'sfvos_check_device': (i32, []),
     'sfvos_frames_to_ndhwc': (i32, [vp, i64, i64, i64, i64, vp, i32, i32, i32, i32, i32, i32, vp]),
     'sfvos_frames_to_groups': (i32, [vp, i64, i64, i64, i64, vp, i32, i32, i32, i32, i32, i64, vp]),
-    'sfvos_frames_to_groups_fp8': (i32, [vp, i64, i64, i64, i64, vp, i32, i32, i32, i32, i64, f32, vp]),
+    'sfvos_frames_to_groups_fp8': (i32, [vp, i64, i64, i64, i64, vp, i32, i32, i32, i32, i64, f32, vp, vp]),
+    'sfvos_frames_absmax': (i32, [vp, i64, i64, i64, i64, i32, i32, i32, i32, vp, vp]),
     'sfvos_pack_weights_fp8': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     'sfvos_ndhwc_to_planar': (i32, [vp, i32, vp, i64, i32, i32, vp]),
     'sfvos_planar_to_ndhwc': (i32, [vp, vp, i32, i64, i32, i32, vp]),
@@ -68,9 +82,9 @@ SIGNATURES = {
     'sfvos_pack_weights_fwd': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     'sfvos_pack_weights_dgrad': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     'sfvos_conv3d_stat_rows': (i32, [PD, C.POINTER(i32)]),
-    'sfvos_conv3d': (i32, [PD, vp, vp, vp, vp, vp, vp, vp]),
+    'sfvos_conv3d': (i32, [PD, vp, vp, vp, vp, vp, vp]),
     'sfvos_conv3d_wgrad_workspace_bytes': (C.c_size_t, [PD]),
-    'sfvos_conv3d_wgrad': (i32, [PD, vp, vp, vp, i32, vp, vp, vp]),
+    'sfvos_conv3d_wgrad': (i32, [PD, vp, vp, vp, i32, vp, vp]),
     'sfvos_bn_finalize': (i32, [vp, i32, C.POINTER(i32), C.POINTER(i64), vp, vp, f32, i32, vp, vp, vp, vp, vp, i32, vp]),
     'sfvos_bn_eval_coeffs': (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp]),
     'sfvos_bn_running_update': (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp]),
@@ -82,6 +96,10 @@ SIGNATURES = {
     'sfvos_reduce_rows': (i32, [vp, i32, i32, vp, i32, vp]),
     'sfvos_sgd_step': (i32, [vp, vp, vp, i64, f32, f32, f32, i32, vp]),
     'sfvos_scale': (i32, [vp, i64, f32, vp]),
+    'sfvos_add_inplace': (i32, [vp, vp, i32, i64, vp]),
+    'sfvos_mse_loss_rows': (i32, [PM]),
+    'sfvos_mse_loss': (i32, [PM, vp, vp, vp]),
+    'sfvos_mse_loss_grad': (i32, [PM, vp, vp]),
     'sfvos_mask_union': (i32, [vp, i32, i64, f32, vp, vp]),
 }
 
@@ -102,6 +120,14 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # the binder's struct mirrors must have the library's sizes (a short struct would be read past its end)
+    sizes = (i32 * 4)()
+    n = lib.sfvos_abi_sizes(sizes, 4)
+    mine = [C.sizeof(ConvDesc), C.sizeof(Pyramid), C.sizeof(Levels), C.sizeof(MseTable)]
+    if lib.sfvos_version() < 200 or n != 4 or list(sizes) != mine:
+        raise RuntimeError('sfvos_amd: %s is ABI revision %d with struct sizes %s, this binding expects revision >= 200 '
+                           'and %s -- rebuild with `python __graft_entry__.py`' % (LIB_PATH, lib.sfvos_version(),
+                                                                                   list(sizes)[:n], mine))
     _lib = lib
     return lib
 

@@ -100,6 +100,26 @@ __device__ __forceinline__ void lds_dma16(const void* base, int records, unsigne
 // ---- host side -------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+int current_device();   // hipGetDevice, -1 on error
+int device_cu_count();  // compute units of the current device (256 when the query fails)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize must be raised once per (kernel, device): one instance per kernel
+// template instantiation (function-local static), one atomic flag per device ordinal.
+struct LdsAttrOnce {
+  static constexpr int MAX_DEV = 64;
+  int done[MAX_DEV] = {};
+  int ensure(const void* kern, int lds_bytes, const char* what) {
+    const int dev = current_device();
+    if (dev >= 0 && dev < MAX_DEV && __atomic_load_n(&done[dev], __ATOMIC_ACQUIRE)) return SFVOS_OK;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) {
+      set_error("%s: hipFuncSetAttribute(%d B LDS) failed: %s", what, lds_bytes, hipGetErrorString(e));
+      return SFVOS_E_LAUNCH;
+    }
+    if (dev >= 0 && dev < MAX_DEV) __atomic_store_n(&done[dev], 1, __ATOMIC_RELEASE);
+    return SFVOS_OK;
+  }
+};
 
 // lateral.hip: dedicated kernel for the lateral (k x 1 x 1) data gradient; -1 = shape not covered
 int lateral_dgrad_try(const sfvos_conv_desc* d, const void* x, const void* w_packed, void* y, hipStream_t stream);

@@ -65,7 +65,6 @@ struct ConvArgs {
   const float* bias;
   char* y;
   float* stat_part;
-  const char* zeros;
   int batch, t_in, t_alloc, t_offset, t_out, c_in, c_out, kt, pad_t, ld_x, ld_y, accumulate;
   // x addressing: element (position, chunk cc of 64 bytes) at x + cc*x_chunk_bytes + position*x_pitch_bytes:
   // pyramid NDHWC = (64, ld_x*ES); channel-group-major input = (group stride in bytes, 64)
@@ -145,7 +144,7 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
   const long long HWp = (long long)H * W;
   // frame 0 of this clip inside the x buffer (t_alloc frames per clip, the conv's window starts at t_offset)
   const long long xfs_bytes = a.lv.xfs[lvl] * a.x_pitch_bytes;  // bytes between consecutive frames of this level
-  const char* xclip = a.x + (a.lv.xpos[lvl] + b * a.lv.xbs[lvl]) * a.x_pitch_bytes + a.t_offset * xfs_bytes;
+  const char* xclip = a.x + (a.lv.xpos[lvl] + b * a.lv.xbs[lvl]) * a.x_pitch_bytes;
 
   f32x16 acc[TT][MT][NT];
 #pragma unroll
@@ -197,12 +196,14 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
   constexpr int NPIECE = NX + NW;
   auto wrap = [](int sl) { return sl >= C::R ? sl - C::R : sl; };
   auto prep_frame = [&](Dma& d, int cc, int i, int slot) {  // halo tile of input frame i, chunk cc -> ring slot
-    const int t = tb0 - a.pad_t + i;
-    const bool t_ok = (unsigned)t < (unsigned)a.t_in;
+    const int t = tb0 - a.pad_t + i, ft = a.t_offset + t;  // frame of the conv's window / of the x buffer
+    // outside the window (temporal padding) or outside the buffer (zero frames "by pointer", model.py:215-225):
+    // an empty descriptor, the copy writes zeros
+    const bool t_ok = (unsigned)t < (unsigned)a.t_in && (unsigned)ft < (unsigned)a.t_alloc;
     d.do_x = true;
-    d.xrec = t_ok ? frame_bytes - (a.x_pitch_bytes > 64 ? cc * 64 : 0) : 0;  // frame outside the clip: all zeros
+    d.xrec = t_ok ? frame_bytes - (a.x_pitch_bytes > 64 ? cc * 64 : 0) : 0;
     d.xb = ring + slot * C::X_BYTES + lds_wave_off;
-    d.xsrc = xclip + (long long)(t_ok ? t : 0) * xfs_bytes + cc * a.x_chunk_bytes;
+    d.xsrc = xclip + (long long)(t_ok ? ft : 0) * xfs_bytes + cc * a.x_chunk_bytes;
   };
   auto prep_w = [&](Dma& d, int cc, int dt, int tg, int s) {  // weight slice of stage s: [TPS taps][4 chunks][BN]
     d.do_w = true;
@@ -499,7 +500,7 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
   const int ncc = (CIN ? CIN : a.c_in) / CK;
   const long long HWp = (long long)H * W;
   const long long xfs_bytes = a.lv.xfs[lvl] * a.x_pitch_bytes;  // bytes between consecutive frames of this level
-  const char* xclip = a.x + (a.lv.xpos[lvl] + b * a.lv.xbs[lvl]) * a.x_pitch_bytes + a.t_offset * xfs_bytes;
+  const char* xclip = a.x + (a.lv.xpos[lvl] + b * a.lv.xbs[lvl]) * a.x_pitch_bytes;
 
   f32x16 acc[M16 ? 1 : (F8 ? HM : MT)];   // 32x32 tiles: [row]
   f32x4 acc16[M16 ? MT : 1][2];  // 16x16 tiles: [row][channel half]
@@ -560,12 +561,14 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
   constexpr int NPIECE = NX + NW;
   auto wrap = [](int sl) { return sl >= C::R ? sl - C::R : sl; };
   auto prep_frame = [&](Dma& d, int cc, int i, int slot) {
-    const int t = tb0 - a.pad_t + i;
+    const int t = tb0 - a.pad_t + i, ft = a.t_offset + t;  // frame of the conv's window / of the x buffer
+    const bool t_ok = (unsigned)t < (unsigned)a.t_in && (unsigned)ft < (unsigned)a.t_alloc;
     d.do_x = true;
-    // frame outside the clip: empty descriptor, all zeros.  (pyramid NDHWC: the chunk offset sits inside the pixel)
-    d.xrec = (unsigned)t < (unsigned)a.t_in ? frame_bytes - (a.x_pitch_bytes > 64 ? cc * 64 : 0) : 0;
+    // frame outside the window or outside the buffer: empty descriptor, all zeros.  (pyramid NDHWC: the chunk
+    // offset sits inside the pixel)
+    d.xrec = t_ok ? frame_bytes - (a.x_pitch_bytes > 64 ? cc * 64 : 0) : 0;
     d.xb = ring + slot * C::X_BYTES + lds_wave_off;
-    d.xsrc = xclip + (long long)((unsigned)t < (unsigned)a.t_in ? t : 0) * xfs_bytes + cc * a.x_chunk_bytes;
+    d.xsrc = xclip + (long long)(t_ok ? ft : 0) * xfs_bytes + cc * a.x_chunk_bytes;
   };
   auto prep_w = [&](Dma& d, int cc, int dt, int s) {  // weight slice of stage s: [9 taps][4 chunks][32]
     d.do_w = true;
@@ -928,7 +931,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_fs_kernel(ConvArgs a) {
 // ---- host-side planning ----------------------------------------------------------------------------
 struct ConvPlan {
   int family;  // 0 narrow 1x1 (c_out <= 32), 1 mid (c_out == 64, 1x1), 2 wide, 3 frame-split (c_out <= 32, 3x3)
-  int TT, NT, TH, BN;
+  int TT, MT, NT, TH, BN;
   int t_blocks, n_blocks, t_out;  // t_blocks = total frame blocks
   int n_launch, l_tt[3], l_blocks[3], l_first[3];  // launches: blocks of l_tt frames starting at frame l_first
   ConvLevels lv;
@@ -956,17 +959,6 @@ static void split_frames(int t_out, int max_tt, ConvPlan* p) {
 // last unit drains: with equal blocks the final round can be nearly empty (362 tiles x 5 blocks = 7.07 rounds
 // of 256 -> 8).  The split is chosen by simulating that greedy dispatch with relative block costs; trading a
 // block of 4 for two of 2 costs some efficiency per frame but lets short blocks fill the tail.
-static int device_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-           prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
-  return cus;
-}
-
 static double greedy_makespan(long long units, const int n[3], const double cost[3], int cus) {
   double t[64]; long long k[64]; int g = 1;  // groups of units that free up at the same time
   t[0] = 0.0; k[0] = cus;
@@ -992,7 +984,7 @@ static double greedy_makespan(long long units, const int n[3], const double cost
 
 static void split_frames_balanced(int t_out, long long units, ConvPlan* p) {
   static const double cost[3] = {1.0, 0.7, 0.5};  // measured relative workgroup times of 4 / 2 / 1 frame blocks
-  const int cus = device_cus();
+  const int cus = device_cu_count();
   int best[3] = {t_out / 4, (t_out % 4) / 2, t_out % 2};
   double best_t = greedy_makespan(units, best, cost, cus);
   for (int n4 = t_out / 4 - 1; n4 >= 0 && n4 >= t_out / 4 - 2; --n4) {
@@ -1001,11 +993,13 @@ static void split_frames_balanced(int t_out, long long units, ConvPlan* p) {
     const double t = greedy_makespan(units, cand, cost, cus);
     if (t < best_t * 0.995) { best_t = t; best[0] = cand[0]; best[1] = cand[1]; best[2] = cand[2]; }
   }
-  if (const char* ov = getenv("SFVOS_FS_SPLIT")) {  // tuning aid: "n4,n2,n1" (must cover t_out exactly)
+#ifdef SFVOS_DIAG  // tuning aid of diagnostic builds only: "n4,n2,n1" (must cover t_out exactly)
+  if (const char* ov = getenv("SFVOS_FS_SPLIT")) {
     int v[3];
     if (sscanf(ov, "%d,%d,%d", &v[0], &v[1], &v[2]) == 3 && v[0] >= 0 && v[1] >= 0 && v[2] >= 0 &&
         4 * v[0] + 2 * v[1] + v[2] == t_out) { best[0] = v[0]; best[1] = v[1]; best[2] = v[2]; }
   }
+#endif
   p->t_blocks = 0;
   p->n_launch = 3;  // parts of the single launch; empty parts have 0 blocks
   int first = 0;
@@ -1020,14 +1014,21 @@ static void split_frames_balanced(int t_out, long long units, ConvPlan* p) {
 
 static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
   SFVOS_REQUIRE(d != nullptr, "conv: null desc");
+  SFVOS_REQUIRE(d->struct_size == (int)sizeof(sfvos_conv_desc),
+                "conv: sfvos_conv_desc.struct_size is %d, this library's struct has %d bytes (stale binding?)",
+                d->struct_size, (int)sizeof(sfvos_conv_desc));
   SFVOS_REQUIRE(d->dtype == SFVOS_F32 || d->dtype == SFVOS_BF16 || d->dtype == SFVOS_FP8, "conv: bad dtype %d", d->dtype);
   SFVOS_REQUIRE(d->taps == 9 || d->taps == 1, "conv: taps must be 9 or 1, got %d", d->taps);
   SFVOS_REQUIRE(d->c_in > 0 && d->c_in % 32 == 0 && d->c_out > 0 && d->c_out % 32 == 0,
                 "conv: channels must be positive multiples of 32 (c_in %d, c_out %d)", d->c_in, d->c_out);
   SFVOS_REQUIRE(d->c_out <= 256, "conv: c_out %d > 256 unsupported", d->c_out);
   SFVOS_REQUIRE(d->batch >= 1 && d->t_in >= 1 && d->kt >= 1, "conv: bad extent");
-  SFVOS_REQUIRE(d->t_offset >= 0 && d->t_alloc >= d->t_offset + d->t_in,
-                "conv: x window [t_offset %d, +t_in %d) exceeds t_alloc %d", d->t_offset, d->t_in, d->t_alloc);
+  SFVOS_REQUIRE(d->t_alloc >= 1, "conv: t_alloc %d", d->t_alloc);
+  // level-major x: the window [t_offset, t_offset + t_in) may stick out of the buffer's t_alloc frames on either side;
+  // those frames are zeros (never read).  The frame-major ring is addressed modulo its slots by the caller: in range.
+  SFVOS_REQUIRE(d->x_frame_stride == 0 || (d->t_offset >= 0 && d->t_alloc >= d->t_offset + d->t_in),
+                "conv: ring window [t_offset %d, +t_in %d) exceeds its %d slots", d->t_offset, d->t_in, d->t_alloc);
+  SFVOS_REQUIRE(d->t_offset > -(1 << 20) && d->t_offset < (1 << 20) && d->t_in < (1 << 20), "conv: window out of range");
   SFVOS_REQUIRE(d->pad_t >= 0 && d->pad_t < d->kt + 1, "conv: bad pad_t %d", d->pad_t);
   const int ce = d->dtype == SFVOS_BF16 ? 8 : d->dtype == SFVOS_FP8 ? 16 : 4;
   if (d->dtype == SFVOS_FP8)
@@ -1055,14 +1056,32 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
       units += (long long)d->batch * ceil_div(d->pyr.h[l] > 0 ? d->pyr.h[l] : 1, 8) * ceil_div(d->pyr.w[l] > 0 ? d->pyr.w[l] : 1, 32);
     p->family = 3; split_frames_balanced(p->t_out, units, p); p->NT = 1; p->TH = 8; p->BN = 32;
   } else if (d->c_out <= 32) {
-    p->family = 0; split_frames(p->t_out, 4, p); p->NT = 1; p->TH = 8; p->BN = 32;
+    p->family = 0; split_frames(p->t_out, 4, p); p->MT = 1; p->NT = 1; p->TH = 8; p->BN = 32;
   } else if (d->c_out == 64 && d->taps == 1) {
-    p->family = 1; split_frames(p->t_out, 3, p); p->NT = 2 / WNW; p->TH = 8; p->BN = 64;
+    p->family = 1; split_frames(p->t_out, 3, p); p->MT = 2; p->NT = 2 / WNW; p->TH = 8; p->BN = 64;
   } else {
-    // accumulators: TT x NT tiles of 16 registers per wave: at most 16 tiles per wave
+    // accumulators: TT x MT x NT tiles of 16 registers per wave: at most 9 tiles per wave
     p->family = 2; p->NT = (d->c_out <= 192 ? 6 : 8) / WNW; split_frames(p->t_out, p->NT == 3 ? 3 : 2, p);
-    p->TH = 4;
+    p->MT = 1; p->TH = 4;
     p->BN = 32 * p->NT * WNW;
+    // Data-gradient convs (pad_t = kt-1): most (output frame, temporal tap) pairs of a multi-frame block meet only
+    // padding, but the block multiplies every tap any of its frames needs.  Count the (frame, tap) slots each blocking
+    // multiplies; when single-frame blocks multiply fewer, use them -- with two pixel rows per wave (8 rows x 32 px x
+    // BN per workgroup), which restores the weight re-use the lost frames gave (slow_conv3's data gradient: 2 slots
+    // instead of 4, 0.28 -> 0.17 ms; slow_conv2's: 4 instead of 5, 0.36 -> 0.31 ms).
+    auto slots = [&](int tb0, int tt) {
+      const int lo = d->pad_t - tb0 - (tt - 1) > 0 ? d->pad_t - tb0 - (tt - 1) : 0;
+      const int hi = d->kt - 1 < d->pad_t - tb0 + d->t_in - 1 ? d->kt - 1 : d->pad_t - tb0 + d->t_in - 1;
+      return hi >= lo ? tt * (hi - lo + 1) : 0;
+    };
+    int cur = 0, single = 0;
+    for (int li = 0; li < p->n_launch; ++li)
+      for (int b = 0; b < p->l_blocks[li]; ++b) cur += slots(p->l_first[li] + b * p->l_tt[li], p->l_tt[li]);
+    for (int t = 0; t < p->t_out; ++t) single += slots(t, 1);
+    if (single < cur) {
+      p->n_launch = 1; p->l_tt[0] = 1; p->l_blocks[0] = p->t_out; p->l_first[0] = 0; p->t_blocks = p->t_out; p->TT = 1;
+      p->MT = 2; p->TH = 8;
+    }
   }
   p->n_blocks = ceil_div(d->c_out, p->BN);
   ConvLevels& lv = p->lv;
@@ -1105,15 +1124,8 @@ template <int DT, int TAPS, int TPS, int TT, int MT, int NT, int WS, int WN, int
 static int launch(const ConvArgs& a, long long grid, hipStream_t stream) {
   typedef ConvCfg<DT, TAPS, TPS, TT, MT, NT, WS, WN> C;
   auto kern = conv3d_kernel<DT, TAPS, TPS, TT, MT, NT, WS, WN, CIN>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    if (e != hipSuccess) {
-      set_error("conv: hipFuncSetAttribute(%d B LDS) failed: %s", C::LDS_BYTES, hipGetErrorString(e));
-      return SFVOS_E_LAUNCH;
-    }
-    attr_done = true;
-  }
+  static LdsAttrOnce once;
+  if (int rc = once.ensure((const void*)kern, C::LDS_BYTES, "conv")) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NTHREADS), C::LDS_BYTES, stream, a);
   return check_launch("conv3d");
 }
@@ -1123,15 +1135,8 @@ static int launch_fs(const ConvArgs& a, long long grid, hipStream_t stream) {
   constexpr int LDS = FsCfg<DT, 4, 1>::LDS_BYTES;  // the largest of the three bodies
   static_assert(LDS >= FsCfg<DT, 2, 2>::LDS_BYTES && LDS >= FsCfg<DT, 1, 4>::LDS_BYTES, "LDS of the merged launch");
   auto kern = conv3d_fs_kernel<DT, CIN>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) {
-      set_error("conv: hipFuncSetAttribute(%d B LDS) failed: %s", LDS, hipGetErrorString(e));
-      return SFVOS_E_LAUNCH;
-    }
-    attr_done = true;
-  }
+  static LdsAttrOnce once;
+  if (int rc = once.ensure((const void*)kern, LDS, "conv")) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS, stream, a);
   return check_launch("conv3d_fs");
 }
@@ -1139,7 +1144,7 @@ static int launch_fs(const ConvArgs& a, long long grid, hipStream_t stream) {
 template <int DT, int TAPS>
 static int dispatch(const ConvPlan& p, const ConvArgs& a, long long grid, hipStream_t s) {
 #define SFVOS_CASE(F, TPSv, TTv, MTv, NTv, WSv, WNv) \
-  if (p.family == F && p.TT == TTv && p.NT == NTv) return launch<DT, TAPS, TPSv, TTv, MTv, NTv, WSv, WNv>(a, grid, s);
+  if (p.family == F && p.TT == TTv && p.MT == MTv && p.NT == NTv) return launch<DT, TAPS, TPSv, TTv, MTv, NTv, WSv, WNv>(a, grid, s);
   // two waves per SIMD
   if constexpr (TAPS == 1) {
     // narrow 1x1 (lateral data gradient 64 -> 32): 8 rows x 32 px x TT frames x 32 channels; wave = one row
@@ -1151,9 +1156,11 @@ static int dispatch(const ConvPlan& p, const ConvArgs& a, long long grid, hipStr
     // wide: 4 rows x 32 px x TT frames x 192/256 channels, 3 taps per stage
     SFVOS_CASE(2, 3, 1, 1, 3, 4, 2) SFVOS_CASE(2, 3, 2, 1, 3, 4, 2) SFVOS_CASE(2, 3, 3, 1, 3, 4, 2)
     SFVOS_CASE(2, 3, 1, 1, 4, 4, 2) SFVOS_CASE(2, 3, 2, 1, 4, 4, 2)
+    // single-frame blocks (data gradients): 8 rows x 32 px x 192/256 channels, two rows per wave
+    SFVOS_CASE(2, 3, 1, 2, 3, 4, 2) SFVOS_CASE(2, 3, 1, 2, 4, 4, 2)
   }
 #undef SFVOS_CASE
-  set_error("conv: no kernel instance for family %d TT %d NT %d taps %d", p.family, p.TT, p.NT, TAPS);
+  set_error("conv: no kernel instance for family %d TT %d MT %d NT %d taps %d", p.family, p.TT, p.MT, p.NT, TAPS);
   return SFVOS_E_ARG;
 }
 
@@ -1170,23 +1177,26 @@ extern "C" int sfvos_conv3d_stat_rows(const sfvos_conv_desc* d, int* rows_per_le
 }
 
 extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
-                            float* stat_part, const void* zeros, sfvos_stream_t stream) {
+                            float* stat_part, sfvos_stream_t stream) {
   ConvPlan p;
   int rc = make_plan(d, &p);
   if (rc != SFVOS_OK) return rc;
-  SFVOS_REQUIRE(x && w_packed && y && zeros, "conv: null pointer");
+  SFVOS_REQUIRE(x && w_packed && y, "conv: null pointer");
   SFVOS_REQUIRE(!(stat_part && d->accumulate), "conv: statistics are those of the conv result; not available with accumulate");
   SFVOS_REQUIRE(d->ld_y % (d->dtype == SFVOS_F32 ? 4 : 8) == 0, "conv: ld_y %d must be a multiple of a 16-byte chunk", d->ld_y);
   SFVOS_REQUIRE(d->dtype != SFVOS_FP8 || bias != nullptr, "conv: e4m3 operands need the [2][c_out] (bias, descale) rows");
   SFVOS_REQUIRE(!(d->taps == 1 && p.family == 2), "conv: 1x1 conv with c_out > 64 has no kernel instance");
+  bool lateral_ok = true;
+#ifdef SFVOS_DIAG
+  lateral_ok = !getenv("SFVOS_NO_LATERAL_KERNEL");
+#endif
   if (!bias && !stat_part && d->taps == 1 && d->x_group_stride == 0 && d->x_frame_stride == 0 &&
-      d->y_frame_stride == 0 && !getenv("SFVOS_NO_LATERAL_KERNEL")) {
+      d->y_frame_stride == 0 && lateral_ok) {
     rc = lateral_dgrad_try(d, x, w_packed, y, (hipStream_t)stream);  // lateral data gradient: its own HBM-bound kernel
     if (rc >= 0) return rc;
   }
   ConvArgs a;
   a.x = (const char*)x; a.wp = (const char*)w_packed; a.bias = bias; a.y = (char*)y; a.stat_part = stat_part;
-  a.zeros = (const char*)zeros;
   a.batch = d->batch; a.t_in = d->t_in; a.t_alloc = d->t_alloc; a.t_offset = d->t_offset; a.t_out = p.t_out;
   a.c_in = d->c_in; a.c_out = d->c_out; a.kt = d->kt;
   a.pad_t = d->pad_t; a.ld_x = d->ld_x; a.ld_y = d->ld_y; a.accumulate = d->accumulate;
@@ -1194,7 +1204,10 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
   a.x_pitch_bytes = d->x_group_stride ? 64 : d->ld_x * es;
   a.x_chunk_bytes = d->x_group_stride ? d->x_group_stride * es : 64;
   a.n_blocks = p.n_blocks; a.t_blocks_total = p.t_blocks;
+  a.debug = 0;
+#ifdef SFVOS_DIAG
   { const char* dbg = getenv("SFVOS_CONV_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
+#endif
 #ifdef SFVOS_STAMP
   { const char* sp = getenv("SFVOS_STAMP_PTR"); a.stamps = sp ? (unsigned long long*)strtoull(sp, nullptr, 0) : nullptr; }
 #endif

@@ -17,7 +17,8 @@ struct PlanarView {
 // (one group), the channel-group-major input layout is gdiv = ld = 32, gstride = positions * 32
 template <int DT>
 __global__ __launch_bounds__(256) void to_ndhwc_kernel(const float* __restrict__ src, PlanarView v, char* dst, int ld,
-                                                       int gdiv, long long gstride, float qscale = 1.f) {
+                                                       int gdiv, long long gstride, float qscale = 1.f,
+                                                       int* sat_count = nullptr) {
   constexpr int CE = Elt<DT>::CE;
   __shared__ float tile[64][65];
   const int tid = threadIdx.x;
@@ -37,15 +38,118 @@ __global__ __launch_bounds__(256) void to_ndhwc_kernel(const float* __restrict__
   }
   __syncthreads();
   constexpr int CPR = 64 / CE;  // chunks per tile row
+  int sat = 0;
   for (int i = tid; i < 64 * CPR; i += 256) {
     const int px = i / CPR, ch = i - px * CPR;
     const long long p = p0 + px;
     if (p < HW && c0 + ch * CE < v.C) {
       float f[CE];
 #pragma unroll
-      for (int e = 0; e < CE; ++e) f[e] = DT == SFVOS_FP8 ? tile[ch * CE + e][px] * qscale : tile[ch * CE + e][px];
+      for (int e = 0; e < CE; ++e) {
+        f[e] = DT == SFVOS_FP8 ? tile[ch * CE + e][px] * qscale : tile[ch * CE + e][px];
+        if (DT == SFVOS_FP8) sat += fabsf(f[e]) > 448.f ? 1 : 0;
+      }
       const int c = c0 + ch * CE;
       *(u32x4*)(dst + ((c / gdiv) * gstride + ((long long)t * HW + p) * ld + c % gdiv) * (16 / CE)) = pack<DT>(f);
+    }
+  }
+  if (DT == SFVOS_FP8 && sat_count != nullptr) {  // integer count: order-independent
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sat += __shfl_xor(sat, o);
+    if ((tid & 63) == 0 && sat > 0) atomicAdd(sat_count, sat);
+  }
+}
+
+// max |src| over strided fp32 frames (e4m3 activation-scale calibration); non-negative floats order like their bits
+__global__ __launch_bounds__(256) void frames_absmax_kernel(const float* __restrict__ src, PlanarView v, float* amax) {
+  const long long HW = (long long)v.H * v.W;
+  const long long total = (long long)v.T * v.C * HW;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    long long k = i;
+    const long long p = k % HW; k /= HW;
+    const int c = (int)(k % v.C);
+    const int t = (int)(k / v.C);
+    const int h = (int)(p / v.W), w = (int)(p - (long long)h * v.W);
+    m = fmaxf(m, fabsf(src[t * v.st + c * v.sc + h * v.sh + w * v.sw]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)amax, __builtin_bit_cast(unsigned, m));
+}
+
+// dst += src, 16 bytes per lane
+template <int DT>
+__global__ __launch_bounds__(256) void add_inplace_kernel(char* dst, const char* __restrict__ src, long long chunks) {
+  constexpr int CE = Elt<DT>::CE;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (long long)gridDim.x * 256) {
+    float a[CE], b[CE];
+    unpack<DT>(*(const u32x4*)(dst + i * 16), a);
+    unpack<DT>(*(const u32x4*)(src + i * 16), b);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) a[e] += b[e];
+    *(u32x4*)(dst + i * 16) = pack<DT>(a);
+  }
+}
+
+// ---- stand-in loss: sum_l mean((out_l - target_l)^2) (oracle/slowfast_ref.py proxy_loss) -------------
+constexpr int MSE_ROWS_PER_LEVEL = 128;   // blocks (= partial rows) per tensor
+struct MseTab {
+  int n;
+  const float* out[SFVOS_MAX_LEVELS]; const float* target[SFVOS_MAX_LEVELS]; float* grad[SFVOS_MAX_LEVELS];
+  long long numel[SFVOS_MAX_LEVELS];
+};
+
+// grid = n * MSE_ROWS_PER_LEVEL; block b of level l sums a strided set of 1024-element runs of it in a fixed order
+__global__ __launch_bounds__(256) void mse_partial_kernel(MseTab t, float* part) {
+  __shared__ double red[256];
+  const int l = blockIdx.x / MSE_ROWS_PER_LEVEL, b = blockIdx.x % MSE_ROWS_PER_LEVEL;
+  const float* o = t.out[l];
+  const float* g = t.target[l];
+  const long long n = t.numel[l];
+  double s = 0.0;
+  for (long long i = ((long long)b * 256 + threadIdx.x) * 4; i < n; i += (long long)MSE_ROWS_PER_LEVEL * 1024) {
+    if (i + 4 <= n && (((size_t)(o + i) | (size_t)(g + i)) & 15) == 0) {
+      const f32x4 a = *(const f32x4*)(o + i), c = *(const f32x4*)(g + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = a[e] - c[e]; s += (double)(d * d); }
+    } else {
+      for (long long k = i; k < n && k < i + 4; ++k) { const float d = o[k] - g[k]; s += (double)(d * d); }
+    }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = (float)(red[0] / (double)n);
+}
+
+__global__ __launch_bounds__(64) void mse_final_kernel(const float* part, int rows, float* loss) {
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < rows; ++i) s += (double)part[i];
+    loss[0] = (float)s;
+  }
+}
+
+__global__ __launch_bounds__(256) void mse_grad_kernel(MseTab t, const float* upstream) {
+  const int l = blockIdx.y;
+  const float* o = t.out[l];
+  const float* g = t.target[l];
+  float* d = t.grad[l];
+  const long long n = t.numel[l];
+  const float k = (upstream ? upstream[0] : 1.f) * 2.f / (float)n;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
+    if (i + 4 <= n && (((size_t)(o + i) | (size_t)(g + i) | (size_t)(d + i)) & 15) == 0) {
+      const f32x4 a = *(const f32x4*)(o + i), c = *(const f32x4*)(g + i);
+      f32x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = k * (a[e] - c[e]);
+      *(f32x4*)(d + i) = r;
+    } else {
+      for (long long q = i; q < n && q < i + 4; ++q) d[q] = k * (o[q] - g[q]);
     }
   }
 }
@@ -225,15 +329,78 @@ extern "C" int sfvos_frames_to_groups(const float* src, int64_t st, int64_t sc, 
 
 extern "C" int sfvos_frames_to_groups_fp8(const float* src, int64_t st, int64_t sc, int64_t sh, int64_t sw, void* dst,
                                           int T, int C, int H, int W, int64_t group_stride, float scale,
-                                          sfvos_stream_t stream) {
+                                          int* sat_count, sfvos_stream_t stream) {
   SFVOS_REQUIRE(src && dst && T > 0 && C > 0 && H > 0 && W > 0 && scale > 0.f, "frames_to_groups_fp8: bad argument");
   SFVOS_REQUIRE(C % 64 == 0 && group_stride >= (int64_t)T * H * W * 64 && group_stride % 16 == 0,
                 "frames_to_groups_fp8: C must be a multiple of 64 and group_stride >= T*H*W*64");
   PlanarView v{st, sc, sh, sw, T, C, H, W};
   dim3 grid((unsigned)ceil_div64((int64_t)H * W, 64), (unsigned)ceil_div(C, 64), (unsigned)T);
   hipLaunchKernelGGL(to_ndhwc_kernel<SFVOS_FP8>, grid, dim3(256), 0, (hipStream_t)stream, src, v, (char*)dst, 64, 64,
-                     (long long)group_stride, scale);
+                     (long long)group_stride, scale, sat_count);
   return check_launch("frames_to_groups_fp8");
+}
+
+extern "C" int sfvos_frames_absmax(const float* src, int64_t st, int64_t sc, int64_t sh, int64_t sw, int T, int C,
+                                   int H, int W, float* amax, sfvos_stream_t stream) {
+  SFVOS_REQUIRE(src && amax && T > 0 && C > 0 && H > 0 && W > 0, "frames_absmax: bad argument");
+  PlanarView v{st, sc, sh, sw, T, C, H, W};
+  hipLaunchKernelGGL(frames_absmax_kernel, dim3(grid_for((long long)T * C * H * W, 256 * 8)), dim3(256), 0,
+                     (hipStream_t)stream, src, v, amax);
+  return check_launch("frames_absmax");
+}
+
+extern "C" int sfvos_add_inplace(void* dst, const void* src, int dtype, int64_t n, sfvos_stream_t stream) {
+  SFVOS_REQUIRE(dst && src && n > 0 && n % 8 == 0, "add_inplace: n must be a positive multiple of 8");
+  SFVOS_REQUIRE((((size_t)dst | (size_t)src) & 15) == 0, "add_inplace: pointers must be 16-byte aligned");
+  const long long chunks = n / (dtype == SFVOS_BF16 ? 8 : 4);
+  hipStream_t s = (hipStream_t)stream;
+  DT_DISPATCH(dtype,
+              hipLaunchKernelGGL(add_inplace_kernel<SFVOS_F32>, dim3(grid_for(chunks, 256 * 4)), dim3(256), 0, s,
+                                 (char*)dst, (const char*)src, chunks),
+              hipLaunchKernelGGL(add_inplace_kernel<SFVOS_BF16>, dim3(grid_for(chunks, 256 * 4)), dim3(256), 0, s,
+                                 (char*)dst, (const char*)src, chunks));
+  return check_launch("add_inplace");
+}
+
+static int mse_table(const sfvos_mse_table* t, MseTab* m, bool need_grad, const char* what) {
+  SFVOS_REQUIRE(t != nullptr && t->n >= 1 && t->n <= SFVOS_MAX_LEVELS, "%s: bad table", what);
+  m->n = t->n;
+  for (int l = 0; l < SFVOS_MAX_LEVELS; ++l) {
+    const bool live = l < t->n;
+    if (live)
+      SFVOS_REQUIRE(t->out[l] && t->target[l] && t->numel[l] > 0 && (!need_grad || t->grad[l]),
+                    "%s: level %d has a null pointer or no elements", what, l);
+    m->out[l] = live ? t->out[l] : nullptr; m->target[l] = live ? t->target[l] : nullptr;
+    m->grad[l] = live ? t->grad[l] : nullptr; m->numel[l] = live ? t->numel[l] : 0;
+  }
+  return SFVOS_OK;
+}
+
+extern "C" int sfvos_mse_loss_rows(const sfvos_mse_table* t) {
+  if (t == nullptr || t->n < 1 || t->n > SFVOS_MAX_LEVELS) return SFVOS_E_ARG;
+  return t->n * MSE_ROWS_PER_LEVEL;
+}
+
+extern "C" int sfvos_mse_loss(const sfvos_mse_table* t, float* part, float* loss, sfvos_stream_t stream) {
+  MseTab m;
+  int rc = mse_table(t, &m, false, "mse_loss");
+  if (rc) return rc;
+  SFVOS_REQUIRE(part && loss, "mse_loss: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(mse_partial_kernel, dim3(m.n * MSE_ROWS_PER_LEVEL), dim3(256), 0, s, m, part);
+  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, s, (const float*)part, m.n * MSE_ROWS_PER_LEVEL, loss);
+  return check_launch("mse_loss");
+}
+
+extern "C" int sfvos_mse_loss_grad(const sfvos_mse_table* t, const float* upstream, sfvos_stream_t stream) {
+  MseTab m;
+  int rc = mse_table(t, &m, true, "mse_loss_grad");
+  if (rc) return rc;
+  long long big = 0;
+  for (int l = 0; l < m.n; ++l) big = m.numel[l] > big ? m.numel[l] : big;
+  hipLaunchKernelGGL(mse_grad_kernel, dim3(grid_for(big, 1024, 1024u), m.n), dim3(256), 0, (hipStream_t)stream, m,
+                     upstream);
+  return check_launch("mse_loss_grad");
 }
 
 extern "C" int sfvos_pack_weights_fp8(const float* w, const float* bias, void* packed, float* bias_descale, int c_out,

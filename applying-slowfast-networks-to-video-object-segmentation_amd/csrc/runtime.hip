@@ -23,9 +23,34 @@ int check_launch(const char* what) {
   return SFVOS_OK;
 }
 
+int current_device() {
+  int dev = -1;
+  return hipGetDevice(&dev) == hipSuccess ? dev : -1;
+}
+
+int device_cu_count() {
+  static int cus[LdsAttrOnce::MAX_DEV] = {};
+  const int dev = current_device();
+  if (dev < 0 || dev >= LdsAttrOnce::MAX_DEV) return 256;
+  int c = __atomic_load_n(&cus[dev], __ATOMIC_ACQUIRE);
+  if (c == 0) {
+    hipDeviceProp_t prop;
+    c = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    __atomic_store_n(&cus[dev], c, __ATOMIC_RELEASE);
+  }
+  return c;
+}
+
 }  // namespace sfvos
 
-extern "C" int sfvos_version(void) { return 100; }
+extern "C" int sfvos_version(void) { return 200; }
+
+extern "C" int sfvos_abi_sizes(int* sizes, int n) {
+  const int v[4] = {(int)sizeof(sfvos_conv_desc), (int)sizeof(sfvos_pyramid), (int)sizeof(sfvos_levels),
+                    (int)sizeof(sfvos_mse_table)};
+  for (int i = 0; i < 4 && i < n && sizes; ++i) sizes[i] = v[i];
+  return 4;
+}
 
 extern "C" const char* sfvos_last_error(void) { return sfvos::g_err; }
 

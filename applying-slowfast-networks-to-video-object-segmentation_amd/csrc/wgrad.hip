@@ -38,7 +38,6 @@ struct WgradArgs {
   const char* x;
   const char* dy;
   float* slab;
-  const char* zeros;
   int t_in, t_alloc, t_offset, t_out, c_in, c_out, kt, ld_x, ld_y, batch;
   long long x_group_bytes;  // 0: x is pyramid NDHWC (pitch ld_x); else bytes between its 64-byte channel groups (bf16)
   int n_blocks, c_blocks, dt_blocks, psplit;
@@ -89,14 +88,17 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   const int nt = wv % NTN, ct = (wv / NTN) % NTC, dg = wv / (NTN * NTC);
   const int r = lane & 31, hh = lane >> 5;
 
-  // XCD-aware order (speed only): the dt_blocks * n_blocks workgroups that sweep the SAME pixel tiles of
-  // the same c-block (they read the same x tiles) get ids equal mod 8 and adjacent in time.
-  const int G = a.dt_blocks * a.n_blocks, psg_n = (a.psplit + 7) >> 3;
-  int q = blockIdx.x >> 3;
-  const int ps = (q / G % psg_n) * 8 + (blockIdx.x & 7);
-  if (ps >= a.psplit) return;  // padding workgroup
-  const int g = q % G; q /= G * psg_n;
-  const int cb = q, nb = g % a.n_blocks, db = g / a.n_blocks;
+  // XCD-aware order (speed only, never correctness): workgroup ids are dealt round-robin over the 8 XCDs, so XCD x
+  // runs ids x, x+8, ... in that order.  Logical work item L = ps * col + (cb * G + g): the col = c_blocks * G
+  // workgroups of one pixel split ps read the same x / dy tiles.  XCD x takes the CONTIGUOUS range
+  // [x*q + min(x,r), ...) of q or q+1 items (N = 8 q + r): every XCD gets the same number of workgroups (+-1) for
+  // ANY split count, and the sharers of a tile sit on one XCD, adjacent in time.
+  const int G = a.dt_blocks * a.n_blocks, col = G * a.c_blocks, N = a.psplit * col;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nq = N >> 3, nr = N & 7;
+  if (slot >= nq + (xcd < nr ? 1 : 0)) return;  // padding workgroup (N not a multiple of 8)
+  const int L = xcd * nq + min(xcd, nr) + slot;
+  const int ps = L / col, ci = L - ps * col;
+  const int cb = ci / G, g = ci - cb * G, nb = g % a.n_blocks, db = g / a.n_blocks;
   const int n_base = nb * NTN * 32, c_base = cb * NTC * 32, dt0 = db * DG;
   const int dt_live = min(DG, a.kt - dt0);      // temporal taps of this group that exist
   const int nxf = a.t_out + dt_live - 1;        // x frames per tile: t = dt0 .. dt0 + nxf - 1
@@ -143,7 +145,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     const long long HWp = (long long)H * W;
     const int pitch = a.x_group_bytes ? 64 : a.ld_x * ES;  // bytes per position
     x_fstride = HWp * pitch;
-    x_frame0 = a.x + (a.lv.xpos[lvl] + ((long long)b * a.t_alloc + a.t_offset + dt0) * HWp) * pitch;
+    x_frame0 = a.x + (a.lv.xpos[lvl] + (long long)b * a.t_alloc * HWp) * pitch;  // frame 0 of the clip's buffer
 #pragma unroll
     for (int it = 0; it < NXP; ++it) {
       const int sl = it * 512 + tid;
@@ -175,8 +177,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   struct Copy { const char* src; char* dst; int rec; };
   auto begin_x = [&](Copy& c) {  // next x tile of the load order -> ring slot xi_q % R
     if (xi_f == nxf) { xi_f = 0; enter_tile_x(++xi_tile); }
-    c.src = x_frame0 + (long long)xi_f * x_fstride;
-    c.rec = (int)x_fstride;
+    const int ft = a.t_offset + dt0 + xi_f;  // frame of the x buffer; outside it: a zero frame (empty descriptor)
+    const bool f_ok = (unsigned)ft < (unsigned)a.t_alloc;
+    c.src = x_frame0 + (long long)(f_ok ? ft : 0) * x_fstride;
+    c.rec = f_ok ? (int)x_fstride : 0;
     c.dst = xbase + (xi_q % R) * C::X_BYTES + lds_wave_off;
     ++xi_f; ++xi_q;
   };
@@ -400,19 +404,11 @@ struct WgradPlan {
   WgradLevels lv;
 };
 
-static int wgrad_cus() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-           prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-  }
-  return cus;
-}
-
 static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
   SFVOS_REQUIRE(d != nullptr, "wgrad: null desc");
+  SFVOS_REQUIRE(d->struct_size == (int)sizeof(sfvos_conv_desc),
+                "wgrad: sfvos_conv_desc.struct_size is %d, this library's struct has %d bytes (stale binding?)",
+                d->struct_size, (int)sizeof(sfvos_conv_desc));
   SFVOS_REQUIRE(d->dtype == SFVOS_F32 || d->dtype == SFVOS_BF16, "wgrad: bad dtype");
   SFVOS_REQUIRE(d->taps == 9 || d->taps == 1, "wgrad: taps must be 9 or 1");
   SFVOS_REQUIRE(d->c_in % 32 == 0 && d->c_out % 32 == 0 && d->c_in > 0 && d->c_out > 0, "wgrad: channels % 32");
@@ -440,7 +436,8 @@ static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
   }
   p->TH = f32 ? 4 : 8;
   SFVOS_REQUIRE(d->pyr.n_levels >= 1 && d->pyr.n_levels <= SFVOS_MAX_LEVELS, "wgrad: n_levels out of range");
-  SFVOS_REQUIRE(d->batch >= 1 && d->t_offset >= 0 && d->t_alloc >= d->t_offset + d->t_in, "wgrad: bad x window");
+  SFVOS_REQUIRE(d->batch >= 1 && d->t_alloc >= 1 && d->t_offset > -(1 << 20) && d->t_offset < (1 << 20) &&
+                d->t_in < (1 << 20), "wgrad: bad x window");  // frames of the window outside [0, t_alloc) are zeros
   WgradLevels& lv = p->lv;
   lv.n = d->pyr.n_levels;
   long long tiles = 0, px = 0;
@@ -465,22 +462,28 @@ static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
   p->dt_blocks = ceil_div(d->kt, p->DG);
   p->ntiles = (int)tiles;
   const int col_blocks = p->n_blocks * p->c_blocks * p->dt_blocks;
-  // Pixel split (split-K): workgroup ids are dealt round-robin over the 8 XCDs and the kernel keeps the pixel split
-  // ps on XCD ps % 8, so an XCD runs col_blocks * psplit/8 workgroups, one per CU at a time.  Choose psplit = 8 m
-  // so that this fills k whole rounds of the XCD's CUs, trading idle CUs in the last round (want m large) against
-  // slab traffic (one fp32 slab written and re-read per split: want m small).
-  const int cus_xcd = wgrad_cus() / 8 > 0 ? wgrad_cus() / 8 : 32;
+  // Pixel split (split-K): N = col_blocks * psplit workgroups, one per compute unit at a time (LDS), dealt evenly over
+  // the XCDs (see the kernel).  A split costs one fp32 slab written and re-read; too few splits leave units idle in the
+  // last round.  Candidates: the split counts that fill k = 1..4 whole rounds of the chip as closely as possible.
+  const int cus = device_cu_count() > 0 ? device_cu_count() : 256;
   const double t_mma = 2.0 * d->c_in * d->c_out * d->kt * d->taps * (double)p->t_out * px * d->batch / 1.0e15;
   const double t_slab = 2.0 * 4.0 * d->c_out * d->c_in * d->kt * d->taps / 3.0e12;  // per split: write + read
-  int ps = 8;
+  int ps = 1;
   double best = 1e30;
   for (int k = 1; k <= 4; ++k) {
-    const int m = (cus_xcd * k) / col_blocks;
-    if (m < 1) continue;
-    const double cost = t_mma * (double)(cus_xcd * k) / (double)(col_blocks * m) + 8.0 * m * t_slab;
-    if (cost < best) { best = cost; ps = 8 * m; }
+    int m = (cus * k) / col_blocks;
+    if (m < 1) m = 1;
+    if (m > p->ntiles) m = p->ntiles;
+    const int per_m = ceil_div(p->ntiles, m);          // tiles per workgroup
+    const int m_eff = ceil_div(p->ntiles, per_m);      // splits that are not empty
+    const int rounds = ceil_div(m_eff * col_blocks, cus);
+    // a round lasts as long as a workgroup: per_m tiles of the ntiles, on 1/col_blocks of the output
+    const double cost = t_mma * (double)rounds * cus * per_m / ((double)p->ntiles * col_blocks) + m_eff * t_slab;
+    if (cost < best) { best = cost; ps = m_eff; }
   }
-  if (const char* ov = getenv("SFVOS_WGRAD_SPLIT")) ps = atoi(ov) > 0 ? atoi(ov) : ps;  // tuning aid
+#ifdef SFVOS_DIAG  // tuning aid of diagnostic builds only
+  if (const char* ov = getenv("SFVOS_WGRAD_SPLIT")) ps = atoi(ov) > 0 ? atoi(ov) : ps;
+#endif
   if (ps > p->ntiles) ps = p->ntiles;
   if (ps < 1) ps = 1;
   const int per = ceil_div(p->ntiles, ps);  // no empty splits
@@ -492,15 +495,8 @@ template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R>
 static int launch_wgrad(const WgradArgs& a, long long grid, hipStream_t stream) {
   typedef WgradCfg<DT, TAPS, NTN, NTC, DG, TH, R> C;
   auto kern = wgrad_kernel<DT, TAPS, NTN, NTC, DG, TH, R>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    if (e != hipSuccess) {
-      set_error("wgrad: hipFuncSetAttribute(%d B LDS) failed: %s", C::LDS_BYTES, hipGetErrorString(e));
-      return SFVOS_E_LAUNCH;
-    }
-    attr_done = true;
-  }
+  static LdsAttrOnce once;
+  if (int rc = once.ensure((const void*)kern, C::LDS_BYTES, "wgrad")) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), C::LDS_BYTES, stream, a);
   return check_launch("wgrad");
 }
@@ -516,13 +512,13 @@ extern "C" size_t sfvos_conv3d_wgrad_workspace_bytes(const sfvos_conv_desc* d) {
 }
 
 extern "C" int sfvos_conv3d_wgrad(const sfvos_conv_desc* d, const void* x, const void* dy, float* grad_w,
-                                  int accumulate, void* workspace, const void* zeros, sfvos_stream_t stream) {
+                                  int accumulate, void* workspace, sfvos_stream_t stream) {
   WgradPlan p;
   int rc = make_wgrad_plan(d, &p);
   if (rc != SFVOS_OK) return rc;
-  SFVOS_REQUIRE(x && dy && grad_w && workspace && zeros, "wgrad: null pointer");
+  SFVOS_REQUIRE(x && dy && grad_w && workspace, "wgrad: null pointer");
   WgradArgs a;
-  a.x = (const char*)x; a.dy = (const char*)dy; a.slab = (float*)workspace; a.zeros = (const char*)zeros;
+  a.x = (const char*)x; a.dy = (const char*)dy; a.slab = (float*)workspace;
   a.t_in = d->t_in; a.t_alloc = d->t_alloc; a.t_offset = d->t_offset; a.t_out = p.t_out; a.c_in = d->c_in;
   a.c_out = d->c_out; a.kt = d->kt;
   a.ld_x = d->ld_x; a.ld_y = d->ld_y; a.batch = d->batch;
@@ -530,8 +526,8 @@ extern "C" int sfvos_conv3d_wgrad(const sfvos_conv_desc* d, const void* x, const
   a.n_blocks = p.n_blocks; a.c_blocks = p.c_blocks;
   a.dt_blocks = p.dt_blocks; a.psplit = p.psplit;
   a.ntiles = p.ntiles; a.lv = p.lv;
-  // psplit padded to a multiple of 8 (XCD-aware order in the kernel; padding workgroups exit at once)
-  const long long grid = (long long)ceil_div(p.psplit, 8) * 8 * p.n_blocks * p.c_blocks * p.dt_blocks;
+  // padded to a multiple of 8 (XCD-aware order in the kernel; padding workgroups exit at once)
+  const long long grid = ceil_div64((long long)p.psplit * p.n_blocks * p.c_blocks * p.dt_blocks, 8) * 8;
   hipStream_t s = (hipStream_t)stream;
   const bool bf = d->dtype == SFVOS_BF16;
   switch (p.cfg) {

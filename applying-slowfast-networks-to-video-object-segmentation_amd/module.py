@@ -111,14 +111,26 @@ class PackedClip(object):
            chunk at a time; in this layout every 128-byte line they touch is used whole (fewer L2 misses).
     """
 
-    def __init__(self, data, shapes, batch, frames, keys=None):
+    def __init__(self, data, shapes, batch, frames, keys=None, pad=(0, 0)):
+        """frames: frames per clip the buffer STORES.  pad = (before, after): zero frames in front of / behind them that
+        complete the fast window (pad[0] + frames + pad[1] = fast_pathway_size) -- the reference's zero feature padding
+        beyond the ends of a sequence (model.py:215-225), handed over "by pointer": the padding frames have no storage
+        and are never read (sfvos_conv_desc.t_offset / t_alloc)."""
         self.data, self.shapes, self.batch, self.frames = data, [tuple(s) for s in shapes], batch, frames
         self.keys = list(keys) if keys is not None else [str(i) for i in range(len(shapes))]
+        self.pad = (int(pad[0]), int(pad[1]))
+        if self.pad[0] < 0 or self.pad[1] < 0 or frames < 1:
+            raise ValueError('PackedClip: pad must be non-negative and at least one frame stored')
         M = batch * frames * sum(h * w for h, w in self.shapes)
         ok = (data.dim() == 2 and data.shape[0] == M) or (data.dim() == 3 and data.shape[1] == M and data.shape[2] == 32)
         if not ok:
             raise ValueError('PackedClip: data must be [%d, C] (ndhwc) or [C/32, %d, 32] (grouped), got %s'
                              % (M, M, tuple(data.shape)))
+
+    @property
+    def window(self):
+        """Frames of the fast window this clip stands for (stored + zero padding)."""
+        return self.pad[0] + self.frames + self.pad[1]
 
     @property
     def layout(self):
@@ -129,8 +141,8 @@ class PackedClip(object):
         return self.data.shape[0] * 32 if self.data.dim() == 3 else self.data.shape[1]
 
     @staticmethod
-    def from_levels(levels, keys=None, layout='ndhwc'):
-        """levels: list of [B,T,H,W,C] tensors (one per FPN level) -> PackedClip (copies once)."""
+    def from_levels(levels, keys=None, layout='ndhwc', pad=(0, 0)):
+        """levels: list of [B,T,H,W,C] tensors (one per FPN level, the T STORED frames) -> PackedClip (copies once)."""
         B, T = levels[0].shape[0], levels[0].shape[1]
         shapes = [tuple(x.shape[2:4]) for x in levels]
         if layout == 'grouped':
@@ -142,12 +154,12 @@ class PackedClip(object):
             data = torch.cat([x.reshape(-1, x.shape[-1]) for x in levels], 0)
         else:
             raise ValueError("PackedClip layout must be 'ndhwc' or 'grouped'")
-        return PackedClip(data, shapes, B, T, keys)
+        return PackedClip(data, shapes, B, T, keys, pad)
 
 
 class _State(object):
     """What one forward leaves behind for its backward."""
-    __slots__ = ('B', 'shapes', 'bufs', 'coef', 'train', 'dtype_name', 'slow_offset')
+    __slots__ = ('B', 'shapes', 'bufs', 'coef', 'train', 'dtype_name', 'slow_offset', 'x_frames', 'x_pad')
 
 
 def _lv_total(lv):
@@ -179,8 +191,8 @@ class SlowFastLayers(nn.Module):
         if self.precision not in _DT:
             raise ValueError("precision must be 'fp32', 'bf16' or 'fp8', got %r" % (self.precision,))
         self.fp8_input_scale = 32.0   # e4m3 activation scale of the input clip (|x| * scale must stay below 448)
+        self._fp8_sat = None          # device int: input elements that saturated in e4m3 since the last check
         self._packs = {}     # (conv name, kind, dtype) -> ((param version, data_ptr, epoch), packed tensor)
-        self._zeros = None
         self._timer = None
         self._side = None
         self.n_streams = int(os.environ.get('SFVOS_STREAMS', '2'))
@@ -188,6 +200,37 @@ class SlowFastLayers(nn.Module):
     def enable_kernel_timer(self):
         self._timer = KernelTimer()
         return self._timer
+
+    # ------------------------------------------------------------------ e4m3 activation scale (precision='fp8')
+    def fp8_saturated(self, reset=True):
+        """Input elements that exceeded the e4m3 range (|x| * fp8_input_scale > 448, stored as +-448) since the
+        last call -- FPN features are unbounded conv outputs, so a fixed scale has to be checked against the data.
+        Synchronises the device."""
+        if self._fp8_sat is None:
+            return 0
+        n = int(self._fp8_sat.item())
+        if reset:
+            self._fp8_sat.zero_()
+        return n
+
+    def calibrate_fp8_scale(self, fast_features, headroom=2.0):
+        """Set fp8_input_scale = 448 / (headroom * max|x|) from representative inputs (same structure as the
+        fast_features argument of temporally_enhance_features: list of dict level -> [T,C,H,W] fp32 on the GPU)."""
+        _lib.load()
+        amax = None
+        for feats in fast_features:
+            for v in feats.values():
+                if not v.is_cuda:
+                    raise RuntimeError('calibrate_fp8_scale runs on the GPU through libsfvos.so (no CPU fallback)')
+                s = v if v.dtype == torch.float32 else v.float()
+                if amax is None:
+                    amax = torch.zeros(1, dtype=torch.float32, device=s.device)
+                _lib.call('sfvos_frames_absmax', _ptr(s), s.stride(0), s.stride(1), s.stride(2), s.stride(3),
+                          s.shape[0], s.shape[1], s.shape[2], s.shape[3], _ptr(amax), _stream())
+        m = float(amax.item()) if amax is not None else 0.0
+        if m > 0.0:
+            self.fp8_input_scale = 448.0 / (headroom * m)
+        return self.fp8_input_scale
 
     def _t(self, kind, layer):
         if self._timer is None:
@@ -203,11 +246,6 @@ class SlowFastLayers(nn.Module):
         w = self.fast_conv1.weight
         if w.device != ref.device:
             raise RuntimeError('module parameters are on %s but inputs on %s' % (w.device, ref.device))
-
-    def _zero_page(self, device):
-        if self._zeros is None or self._zeros.device != device:
-            self._zeros = torch.zeros(1024, dtype=torch.uint8, device=device)
-        return self._zeros
 
     def _packed(self, layer, kind, dt_name):
         dt_id, tdt = _DT[dt_name]
@@ -265,11 +303,16 @@ class SlowFastLayers(nn.Module):
         d.ld_x, d.ld_y, d.accumulate = ld_x, ld_y, accumulate
         return d
 
-    def _src_window(self, layer, slow_offset):
-        """(buffer name, t_alloc, t_offset) of a layer's input: the slow pathway's first conv reads its
-        centre frames straight out of the fast clip when the caller's slow tensor aliases it."""
+    def _src_window(self, layer, slow_offset, x_frames=None, x_pad=0):
+        """(buffer name, t_alloc, t_offset) of a layer's input.  The slow pathway's first conv reads its centre frames
+        straight out of the fast clip when the caller's slow tensor aliases it; a clip that stores only x_frames of
+        the fast window behind x_pad zero frames (PackedClip.pad) is addressed with a shifted window: the frames
+        that fall outside its buffer are zero frames the kernels never read."""
+        fp = self.plan.fp if x_frames is None else x_frames
         if layer.src == 'xs0' and slow_offset is not None:
-            return 'xf0', self.plan.fp, slow_offset
+            return 'xf0', fp, slow_offset - x_pad
+        if layer.src == 'xf0' and x_frames is not None:
+            return 'xf0', fp, -x_pad
         return layer.src, None, 0
 
     # ------------------------------------------------------------------ streams
@@ -290,7 +333,7 @@ class SlowFastLayers(nn.Module):
         return layer.name[0] in 'sl'
 
     # ------------------------------------------------------------------ forward engine (whole pyramid)
-    def _engine_forward(self, shapes, B, xf0, xs0, slow_offset, keep):
+    def _engine_forward(self, shapes, B, xf0, xs0, slow_offset, keep, x_frames=None, x_pad=0):
         """xf0 / xs0: flat pyramid buffers [B*T*sum(HW), C] in the compute dtype (xs0 None when the slow
         clip aliases frames [slow_offset, slow_offset+sp) of the fast clip).
         Returns (list of merged [B,256,H,W] fp32 per level, state or None)."""
@@ -299,7 +342,6 @@ class SlowFastLayers(nn.Module):
         dt_name = 'bf16' if fp8 else self.precision
         dt_id, tdt = _DT[dt_name]
         dev = xf0.device
-        zeros = self._zero_page(dev)
         L = len(shapes)
         if fp8 and (self.training or keep):
             raise RuntimeError("precision='fp8' is inference-only (eval mode, no autograd state): the e4m3 path has "
@@ -322,7 +364,7 @@ class SlowFastLayers(nn.Module):
                 if name not in bufs:
                     b = plan.buffers[name]
                     bufs[name] = torch.empty((B * b.frames * pix, b.channels), dtype=tdt, device=dev)
-            sname, t_alloc, t_off = self._src_window(l, slow_offset)
+            sname, t_alloc, t_off = self._src_window(l, slow_offset, x_frames, x_pad)
             src = bufs[sname]
             lv = _lib.make_levels(shapes, B, l.t_out)
             if fp8 and l.name == 'f1':   # e4m3 operands: x = [C/64][M][64] bytes, (bias, descale) rows as `bias`
@@ -373,7 +415,7 @@ class SlowFastLayers(nn.Module):
                 if train:
                     with self._t('conv_fwd', l.name):
                         _lib.call('sfvos_conv3d', ctypes.byref(d), _ptr(src), _ptr(wp), bias, _ptr(raw),
-                                  _ptr(w['part']), _ptr(zeros), st)
+                                  _ptr(w['part']), st)
                     _lib.call('sfvos_bn_finalize', _ptr(w['part']), L, w['rows_pl'], lv.m, _ptr(bn.weight.detach()),
                               _ptr(bn.bias.detach()), float(bn.eps), l.c_out, _ptr(cf[0, _MEAN]), _ptr(cf[0, _RSTD]),
                               _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), _ptr(cf[0, _VARU]), cs, st)
@@ -386,8 +428,7 @@ class SlowFastLayers(nn.Module):
                                   _ptr(cf[0, _MEAN]), _ptr(cf[0, _VARU]), L, cs, l.c_out, float(bn.momentum), st)
                 else:
                     with self._t('conv_fwd', l.name):
-                        _lib.call('sfvos_conv3d', ctypes.byref(d), _ptr(src), _ptr(wp), bias, _ptr(raw), None,
-                                  _ptr(zeros), st)
+                        _lib.call('sfvos_conv3d', ctypes.byref(d), _ptr(src), _ptr(wp), bias, _ptr(raw), None, st)
                     _lib.call('sfvos_bn_eval_coeffs', _ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
                               _ptr(bn.running_mean), _ptr(bn.running_var), float(bn.eps), l.c_out, _ptr(cf[0, _MEAN]),
                               _ptr(cf[0, _RSTD]), _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), st)
@@ -417,6 +458,7 @@ class SlowFastLayers(nn.Module):
         state = _State()
         state.B, state.shapes, state.bufs, state.coef = B, shapes, bufs, coef
         state.train, state.dtype_name, state.slow_offset = train, dt_name, slow_offset
+        state.x_frames, state.x_pad = x_frames, x_pad
         del bufs['out']
         return merged, state
 
@@ -427,7 +469,6 @@ class SlowFastLayers(nn.Module):
         dt_id, tdt = _DT[dt_name]
         B, shapes, bufs, coef = state.B, state.shapes, state.bufs, state.coef
         dev = bufs['xf0'].device
-        zeros = self._zero_page(dev)
         lib = _lib.load()
         pix = sum(h * w for h, w in shapes)
         pyr = _lib.make_pyramid(shapes)
@@ -495,7 +536,7 @@ class SlowFastLayers(nn.Module):
             if need_b:
                 w['bpart'] = torch.empty((rows, l.c_out), dtype=torch.float32, device=dev)
                 w['db'] = gout(l.conv + '.bias', (l.c_out,))
-            sname, t_alloc, t_off = self._src_window(l, state.slow_offset)
+            sname, t_alloc, t_off = self._src_window(l, state.slow_offset, state.x_frames, state.x_pad)
             w['src'] = bufs[sname]
             if need_w:
                 d = self._desc(l, B, pyr, dt_id, w['src'], l.c_out, t_alloc, t_off)
@@ -558,14 +599,14 @@ class SlowFastLayers(nn.Module):
                 if w['need_in']:  # data gradient first: the other pathway may be waiting for it
                     with self._t('conv_dgrad', l.name):
                         _lib.call('sfvos_conv3d', ctypes.byref(w['dd']), _ptr(dx), _ptr(w['wpd']), None,
-                                  _ptr(gb[l.src]), None, _ptr(zeros), st)
+                                  _ptr(gb[l.src]), None, st)
                     if side is not None:
                         ev[l.name] = torch.cuda.Event()
                         ev[l.name].record(stream)
                 if w['need_w']:
                     with self._t('wgrad', l.name):
                         _lib.call('sfvos_conv3d_wgrad', ctypes.byref(w['wd']), _ptr(w['src']), _ptr(dx), _ptr(w['gw']),
-                                  sacc if (l.conv + '.weight') in direct else 0, _ptr(w['ws']), _ptr(zeros), st)
+                                  sacc if (l.conv + '.weight') in direct else 0, _ptr(w['ws']), st)
                     grads[l.conv + '.weight'] = w['gw']
                 if sink is not None:  # this layer's slice of the flat gradient is complete: exchange may start
                     done = [q for q in list(conv.parameters()) + list(bn.parameters())]
@@ -614,6 +655,8 @@ class SlowFastLayers(nn.Module):
         pix = sum(t.shape[3] * t.shape[4] for t in tensors)
         M = B * frames * pix
         flat = torch.empty((C // 64, M, 64), dtype=torch.uint8, device=tensors[0].device)
+        if self._fp8_sat is None or self._fp8_sat.device != flat.device:
+            self._fp8_sat = torch.zeros(1, dtype=torch.int32, device=flat.device)
         st = _stream()
         off = 0
         for t in tensors:
@@ -622,7 +665,7 @@ class SlowFastLayers(nn.Module):
             for b in range(B):
                 _lib.call('sfvos_frames_to_groups_fp8', _ptr(s[b]), s.stride(2), s.stride(1), s.stride(3), s.stride(4),
                           _ptr(flat, (off + b * frames * H * W) * 64), frames, C, H, W, M * 64,
-                          float(self.fp8_input_scale), st)
+                          float(self.fp8_input_scale), _ptr(self._fp8_sat), st)
             off += B * frames * H * W
         return flat
 
@@ -691,9 +734,9 @@ class SlowFastLayers(nn.Module):
                                "clip format in this build")
         plan = self.plan
         _, tdt = _DT[self.precision]
-        if clip.frames != plan.fp or clip.channels != plan.input_size or clip.data.dtype != tdt \
+        if clip.window != plan.fp or clip.channels != plan.input_size or clip.data.dtype != tdt \
                 or not clip.data.is_contiguous():
-            raise RuntimeError('PackedClip must hold %d frames x %d channels, contiguous %s'
+            raise RuntimeError('PackedClip must stand for %d frames (stored + zero padding) x %d channels, contiguous %s'
                                % (plan.fp, plan.input_size, tdt))
         if len(clip.shapes) > _lib.MAX_LEVELS:
             raise RuntimeError('at most %d pyramid levels per call' % _lib.MAX_LEVELS)
@@ -705,7 +748,7 @@ class SlowFastLayers(nn.Module):
         params = [p for _, p in self.named_parameters()]
         keep = torch.is_grad_enabled() and (clip.data.requires_grad or any(p.requires_grad for p in params))
         meta = dict(mode='packed', L=len(clip.shapes), keep=keep, shapes=clip.shapes, B=clip.batch,
-                    slow_offset=slow_offset)
+                    slow_offset=slow_offset, x_frames=clip.frames, x_pad=clip.pad[0])
         merged = _SlowFastPyramidFn.apply(self, meta, names, clip.data, *params)
         return OrderedDict(zip(clip.keys, merged))
 
@@ -735,7 +778,10 @@ class _SlowFastPyramidFn(torch.autograd.Function):
             n_in = 1
             B, shapes, slow_offset = meta['B'], meta['shapes'], meta['slow_offset']
             xf0, xs0 = tensors[0].detach(), None
-        merged, state = module._engine_forward(shapes, B, xf0, xs0, slow_offset, keep)
+        x_frames, x_pad = meta.get('x_frames'), meta.get('x_pad', 0)
+        if x_frames == module.plan.fp and x_pad == 0:
+            x_frames = None   # the whole window is stored
+        merged, state = module._engine_forward(shapes, B, xf0, xs0, slow_offset, keep, x_frames, x_pad)
         ctx.module, ctx.state, ctx.names, ctx.mode, ctx.n_in, ctx.L = module, state, names, meta['mode'], n_in, L
         return tuple(merged)
 
@@ -780,17 +826,26 @@ class _SlowFastPyramidFn(torch.autograd.Function):
         else:
             g = None
             if need_fast:
-                g = gb['xf0'].clone()   # data gradients are pyramid NDHWC [M, C]
-                gs = gb['xs0']  # slow window gradient, added into its frames of the fast clip (plumbing adds)
+                g = gb['xf0']   # data gradients are pyramid NDHWC [M, C]; this buffer is not used again
+                gs = gb['xs0']  # slow window gradient: added into frames [so, so+sp) of the fast clip's gradient
                 sp, fp, so = module.plan.sp, module.plan.fp, state.slow_offset
+                C = g.shape[-1]
                 off_f = off_s = 0
                 for (H, W) in shapes:
                     P = H * W
-                    vf = g[off_f: off_f + B * fp * P].view(B, fp, P, -1)
-                    vs = gs[off_s: off_s + B * sp * P].view(B, sp, P, -1)
-                    vf[:, so: so + sp] += vs
+                    for b in range(B):
+                        _lib.call('sfvos_add_inplace', _ptr(g, (off_f + (b * fp + so) * P) * C),
+                                  _ptr(gs, (off_s + b * sp * P) * C), dt_id, sp * P * C, st)
                     off_f += B * fp * P
                     off_s += B * sp * P
+                if state.x_frames is not None:   # the clip stores only part of the window: hand back those frames
+                    parts, off_f = [], 0
+                    for (H, W) in shapes:
+                        P = H * W
+                        v = g[off_f: off_f + B * fp * P].view(B, fp, P, C)
+                        parts.append(v[:, state.x_pad: state.x_pad + state.x_frames].reshape(-1, C))
+                        off_f += B * fp * P
+                    g = torch.cat(parts, 0)
                 if state.bufs['xf0'].dim() == 3:  # the clip came channel-group-major: hand its gradient back that way
                     g = g.view(g.shape[0], -1, 32).permute(1, 0, 2).contiguous()
             out.append(g)

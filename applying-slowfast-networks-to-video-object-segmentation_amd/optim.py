@@ -55,6 +55,22 @@ class FusedSGD(torch.optim.Optimizer):
         all-reduced as soon as backward has produced it (overlap of the exchange with the rest of backward)."""
         module._grad_sink = self
         self.bucket = bucket
+        if bucket is not None and hasattr(bucket, 'set_buckets'):
+            # coalesced exchange: (layer 3 + laterals), (layer 2), (layer 1) -- each group is one contiguous range of
+            # the flat buffer in the reference's registration order (model.py:47-67: the laterals come last)
+            ranges = []
+            for group in (('f3', 's3', 'l1', 'l2'), ('f2', 's2'), ('f1', 's1')):
+                spans = []
+                for name in group:
+                    l = module.plan.layer(name)
+                    for mod in (getattr(module, l.conv), getattr(module, l.bn)):
+                        spans += [self._span[id(p)] for p in mod.parameters() if id(p) in self._span]
+                if not spans:
+                    continue
+                lo, hi = min(a for a, _ in spans), max(b for _, b in spans)
+                if hi - lo == sum(b - a for a, b in spans):
+                    ranges.append((lo, hi))
+            bucket.set_buckets(ranges)
         return self
 
     def layer_done(self, params, stream=None):

@@ -3,10 +3,13 @@
 
 The reference's SlowFast path is single-process; clips are independent units,
 so they shard across ranks with ONE exchange step per optimiser step: the all-reduce(sum) of the
-flat gradient bucket (3.9 M fp32 at (sp,fp)=(4,32)), averaged by world size.  The collective
-runs on a side stream, layer by layer as backward finishes each layer's gradients (layer 3 and
-the second lateral first), so all but the first layer's share overlaps with the rest of backward;
-the optimiser waits for it.
+flat gradient buffer (3.9 M fp32 at (sp,fp)=(4,32)), averaged by world size.  The collectives
+run on a side stream while backward is still producing the earlier layers' gradients: the flat
+buffer is cut into (at most) three contiguous buckets -- layer 3 + laterals, layer 2, layer 1 --
+and each is all-reduced the moment backward has enqueued the last kernel writing into it, so only
+the first layer's bucket cannot overlap; the optimiser waits for all of them.  xGMI is point to
+point: three collectives of 4-7 MB keep the per-call RCCL launch latency (x3, not x8) small
+against the transfer time while still hiding two of them behind backward.
 BatchNorm statistics stay per replica (the reference has no SyncBN)."""
 import os
 
@@ -43,9 +46,12 @@ class GradBucket(object):
     ran on -- and each range is all-reduced at once on a side stream (RCCL over xGMI) while backward continues with the
     earlier layers; finish() waits for the collectives, reduces whatever was not reported, and applies 1/world."""
 
-    def __init__(self, flat_grad, group=None):
+    def __init__(self, flat_grad, group=None, coalesce=True):
         self.flat = flat_grad
         self.group = group
+        self.coalesce = coalesce   # False: every reported segment is its own collective (A/B)
+        self._buckets = []         # [lo, hi) ranges all-reduced as ONE collective each once fully reported
+        self._ready = []           # segments reported since arm() that have not been sent yet
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._works = []
         self._stream = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
@@ -62,7 +68,9 @@ class GradBucket(object):
     def _launch(self, lo, hi, producer_stream=None):
         part = self.flat[lo:hi]
         if self._stream is not None:
-            self._stream.wait_stream(producer_stream if producer_stream is not None else torch.cuda.current_stream())
+            producers = producer_stream if isinstance(producer_stream, (list, tuple)) else [producer_stream]
+            for ps in producers:
+                self._stream.wait_stream(ps if ps is not None else torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
                 self._works.append(dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
@@ -70,10 +78,20 @@ class GradBucket(object):
         self._sent.append((lo, hi))
 
     # -- overlapped with backward -------------------------------------------------------------------------
+    def set_buckets(self, ranges):
+        """Disjoint [lo, hi) ranges of the flat buffer (FusedSGD.attach derives them from the module's layer
+        table): segments reported inside a bucket are held back until they cover it, then sent as one collective."""
+        ranges = sorted((int(a), int(b)) for a, b in ranges if b > a)
+        for (a0, b0), (a1, b1) in zip(ranges, ranges[1:]):
+            if a1 < b0:
+                raise ValueError('GradBucket: buckets overlap')
+        self._buckets = ranges
+
     def arm(self):
         """The next backward produces the gradients to exchange: accept segment_ready() calls."""
         self._armed = self.world > 1
         self._sent = []
+        self._ready = []
 
     @property
     def armed(self):
@@ -83,26 +101,50 @@ class GradBucket(object):
         """flat[lo:hi] is final (every kernel writing it has been enqueued on producer_stream / the current stream)."""
         if not self._armed or hi <= lo:
             return
-        for a, b in self._sent:
+        for a, b in self._sent + [(r[0], r[1]) for r in self._ready]:
             if lo < b and a < hi:
                 raise RuntimeError('GradBucket: range [%d, %d) reported twice' % (lo, hi))
-        self._launch(lo, hi, producer_stream)
+        bucket = None
+        if self.coalesce:
+            for a, b in self._buckets:
+                if a <= lo and hi <= b:
+                    bucket = (a, b)
+        if bucket is None:
+            self._launch(lo, hi, producer_stream)
+            return
+        self._ready.append((lo, hi, producer_stream))
+        mine = sorted(r for r in self._ready if bucket[0] <= r[0] and r[1] <= bucket[1])
+        pos = bucket[0]
+        for a, b, _ in mine:
+            if a != pos:
+                return          # a hole: some layer of this bucket has not reported yet
+            pos = b
+        if pos != bucket[1]:
+            return
+        # complete: the collective waits for every stream that produced a piece of it
+        self._ready = [r for r in self._ready if r not in mine]
+        streams = []
+        for _, _, st in mine:
+            if st is not None and st not in streams:
+                streams.append(st)
+        self._launch(bucket[0], bucket[1], streams or None)
 
     def finish(self):
         if self.world == 1:
             return
-        if self._armed or self._sent:
-            # whatever backward did not report (parameters outside the module, or no gradient sink attached)
-            covered = sorted(self._sent)
-            pos, gaps = 0, []
-            for a, b in covered:
-                if a > pos:
-                    gaps.append((pos, a))
-                pos = max(pos, b)
-            if pos < self.flat.numel():
-                gaps.append((pos, self.flat.numel()))
-            for a, b in gaps:
-                self._launch(a, b)
+        # whatever has not been handed to the collective yet (nothing at all when neither start() nor arm() ran:
+        # finish() alone is then a whole-buffer all-reduce -- it never scales unreduced gradients)
+        self._ready = []   # held-back segments of incomplete buckets go out with the gaps below
+        covered = sorted(self._sent)
+        pos, gaps = 0, []
+        for a, b in covered:
+            if a > pos:
+                gaps.append((pos, a))
+            pos = max(pos, b)
+        if pos < self.flat.numel():
+            gaps.append((pos, self.flat.numel()))
+        for a, b in gaps:
+            self._launch(a, b)
         self._armed = False
         self._sent = []
         for w in self._works:

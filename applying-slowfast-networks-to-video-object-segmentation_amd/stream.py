@@ -165,7 +165,7 @@ class SlowFastStream(object):
         raw = self.raw[name]
         bias = _ptr(conv.bias.detach()) if conv.bias is not None else None
         _lib.call('sfvos_conv3d', ctypes.byref(d), _ptr(ring.buf), _ptr(self.m._packed(l, 'fwd', self.dt_name)), bias,
-                  _ptr(raw), None, _ptr(self.m._zero_page(self.dev)), st)
+                  _ptr(raw), None, st)
         cf = self.cf[name]
         cs = _CF_ROWS * l.c_out
         if dst is None:

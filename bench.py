@@ -1,26 +1,32 @@
 """bench.py -- clips/s of the SlowFastLayers hot path (fwd + bwd + SGD) on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
-torch.distributed.run with one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it under
+torch.distributed.run with one rank per GPU (RCCL).  Started as a plain `python bench.py --gpus N` (no WORLD_SIZE in
+the environment) it starts the N ranks itself -- as a CHILD `python -m torch.distributed.run ...` process, before
+this process has made any GPU call -- and exits with the child's status.  Rank 0 prints ONE JSON line.
 
 Workload = BASELINE.json configs[1] restated in the reference's own parametrisation:
-(slow, fast) = (4, 32) frames, one clip = one call of temporally_enhance_features over the five FPN
-levels of a 480x854 DAVIS frame (P = 85 932 positions), bf16 activations / f32 accumulate, inputs
-resident in HBM as channels-last clips, synthetic N(0,1) features, random-init weights.
-A step = forward + backward of one clip; gradients are accumulated over 2 clips and then the
-optimiser steps (reference model.py:369-374), with the data-parallel all-reduce in front of it.
+(slow, fast) = (4, 32) frames, one clip = one call of temporally_enhance_features over the five FPN levels of a
+480x854 DAVIS frame (P = 85 932 positions), bf16 activations / f32 accumulate, the clip resident in HBM as a
+channel-group-major bf16 PackedClip ([C/32][positions][32]: SURVEY.md 8f.3 hand-over), synthetic N(0,1) features,
+random-init weights.  A step = forward + loss + backward of one clip; gradients are accumulated over 2 clips and
+then the optimiser steps (reference model.py:369-374), with the data-parallel all-reduce in front of it.
+The loss is the stand-in of SURVEY.md 8d (sum_l mean((out_l - target_l)^2), sfvos_amd.MSEProxyLoss: two libsfvos
+launches); nothing under oracle/ is imported outside cpu_baseline().
+`dropin_api_ms_per_step` times the same step through the reference's calling convention
+(temporally_enhance_features on lists of fp32 NCHW frame tensors, model.py:157-158,340), i.e. including the
+fp32-NCHW -> bf16 layout pass that a train.py caller pays on every call.
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 
 def parse():
@@ -33,66 +39,120 @@ def parse():
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--streams', type=int, default=1,
                     help='HIP streams per clip: 1 = every launch on one stream (clean per-kernel HIP-event / rocprof '
-                         'durations, the default here); 2 = slow pathway on a side stream (module default, ~5 %% '
+                         'durations, the default here); 2 = slow pathway on a side stream (module default, a few %% '
                          'more clips/s, but concurrent kernels stretch each other\'s measured duration)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-dropin', action='store_true', help='skip the drop-in API (fp32 NCHW frame lists) timing')
     ap.add_argument('--ndhwc-input', action='store_true', help='hand the clip over as plain pyramid NDHWC (A/B of the grouped layout)')
     ap.add_argument('--no-grad-sink', action='store_true',
                     help='let autograd accumulate parameter gradients from temporaries (A/B of FusedSGD.attach)')
+    ap.add_argument('--per-layer-allreduce', action='store_true',
+                    help='one all-reduce per layer instead of the 3 coalesced buckets (A/B)')
     ap.add_argument('--cpu-threads', type=int, default=0)
+    ap.add_argument('--cpu-clips', type=int, default=3, help='timed clips of the CPU baseline (after 1 warm-up)')
+    ap.add_argument('--master-port', type=int, default=29541)
     return ap.parse_args()
 
 
-def cpu_baseline(sp, fp, threads):
-    """The oracle (torch-CPU restatement of the reference path) timed on this box's host cores on a
-    bounded sample: ONE clip's FPN level '0' (192x336 = 75 % of the clip's positions, 10-20 s), fwd+bwd."""
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks as a child process.
+    Nothing in this process has touched the GPU (torch is not even imported yet)."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(sp, fp, threads, clips):
+    """The oracle (torch-CPU restatement of the reference path, parity-locked to the reference's class by
+    tests/golden) timed on this box's host cores: whole clips (all five FPN levels through
+    temporally_enhance_features, B = 1), fwd + loss + bwd, SGD(lr 1e-3, momentum 0.9, wd 1e-4) every 2nd clip as
+    model.py:372-374 steps it; 1 warm-up clip, then the median of `clips` timed clips."""
+    import torch
+    from collections import OrderedDict
     from oracle.slowfast_ref import OracleSlowFastLayers, proxy_loss
     from sfvos_amd import davis_pyramid
     if threads > 0:
         torch.set_num_threads(threads)
     cores = torch.get_num_threads()
-    pyr = dict(davis_pyramid())
-    level = '0'
-    H, W = pyr[level]
-    P = sum(h * w for h, w in pyr.values())
+    pyr = davis_pyramid()
     torch.manual_seed(63)
     m = OracleSlowFastLayers(256, torch.device('cpu'), sp, fp)
     m.train()
-    fast = torch.randn(1, 256, fp, H, W)
-    slow = fast[:, :, fp // 2 - sp // 2: fp // 2 + (sp + 1) // 2]
-    t0 = time.time()
-    s, f = m(slow, fast)
-    loss = proxy_loss({level: torch.cat([s, f], 1).squeeze(2)})
-    loss.backward()
-    dt = time.time() - t0
-    frac = float(H * W) / P
-    return {'value': frac / dt, 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
-            'sample': "oracle fwd+bwd of FPN level '%s' (%dx%d, %.1f%% of one clip's positions) in %.1f s, "
-                      "scaled by position share" % (level, H, W, 100 * frac, dt)}
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    fast = OrderedDict((k, torch.randn(fp, 256, h, w)) for k, (h, w) in pyr)
+    idx = fp // 2
+    slow = OrderedDict((k, v[idx - sp // 2: idx + (sp + 1) // 2]) for k, v in fast.items())
+    times = []
+    for i in range(1 + clips):
+        t0 = time.perf_counter()
+        loss = proxy_loss(m.temporally_enhance_features([slow], [fast]))
+        loss.backward()
+        if i % 2 == 1:
+            opt.step()
+            opt.zero_grad()
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times[1:])
+    return {'value': 1.0 / med, 'unit': 'clips/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model(),
+            's_per_clip': round(med, 3),
+            'sample': 'oracle (torch fp32 CPU) fwd+loss+bwd of whole (sp=%d, fp=%d) clips over the 5-level DAVIS '
+                      'pyramid, SGD every 2nd clip; 1 warm-up (%.1f s) + median of %d timed clips (%s s), %d threads'
+                      % (sp, fp, times[0], clips, ', '.join('%.1f' % t for t in times[1:]), cores)}
 
 
-def pmc_traffic(path):
+def pmc_traffic(path, kernel):
     """HBM bytes of the dominant kernel per launch, from the committed rocprofv3 PMC passes of this same
     command (FETCH_SIZE and WRITE_SIZE in separate passes; KB units; gfx950 FETCH_SIZE counts half of a wide
     streaming read, so it is doubled -- MI355X_MICROARCH.md, HBM).  None when the summary is absent."""
     try:
         with open(path) as f:
             s = json.load(f)
-        k = 'conv3d_fs_kernel<1, 256>'
-        return 2.0 * s[k]['FETCH_SIZE']['mean'] * 1024 + s[k]['WRITE_SIZE']['mean'] * 1024
+        return 2.0 * s[kernel]['FETCH_SIZE']['mean'] * 1024 + s[kernel]['WRITE_SIZE']['mean'] * 1024
     except Exception:
         return None
 
 
+def make_step(model, opt, bucket, loss_fn, forward):
+    """One bench step (also driven, at world size 2 over gloo, by tests/test_gpu_dp.py): forward + loss + backward of
+    one clip; every 2nd clip completes the gradients: all-reduce (overlapped with that backward), optimiser step."""
+    def step(i):
+        loss = loss_fn(forward())
+        if i % 2 == 1:  # model.py:372-374: optimiser every 2nd clip: this backward completes the gradients
+            bucket.arm()
+        loss.backward()
+        if i % 2 == 1:
+            bucket.finish()
+            opt.step()
+            opt.zero_grad()
+        return loss
+    return step
+
+
 def main():
     args = parse()
-    from sfvos_amd import FusedSGD, GradBucket, PackedClip, SlowFastLayers, davis_pyramid, init_distributed
-    from oracle.slowfast_ref import proxy_loss  # loss definition only (SURVEY.md 8d stand-in for RoI-head losses)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import torch
+    import torch.distributed as dist
+    from sfvos_amd import (FusedSGD, GradBucket, MSEProxyLoss, PackedClip, SlowFastLayers, davis_pyramid,
+                           init_distributed)
 
     rank, world, local = init_distributed()
-    if world != args.gpus:
-        if rank == 0 and world > 1:
-            print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
     dev = torch.device('cuda', (local % torch.cuda.device_count()) if world > 1 else 0)
     torch.cuda.set_device(dev)
 
@@ -101,35 +161,25 @@ def main():
     model.train()
     model.n_streams = args.streams
     opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
-    bucket = GradBucket(opt.flat_grad)
+    bucket = GradBucket(opt.flat_grad, coalesce=not args.per_layer_allreduce)
     if not args.no_grad_sink:
-        # kernels write parameter gradients straight into the flat gradient buffer; with world > 1 each layer's
-        # slice is all-reduced (RCCL, side stream) as soon as backward has produced it
+        # kernels write parameter gradients straight into the flat gradient buffer; with world > 1 the finished
+        # layers' slices are all-reduced (RCCL, side stream) while backward continues
         opt.attach(model, bucket)
     tdt = torch.bfloat16 if args.precision == 'bf16' else torch.float32
     pyr = davis_pyramid()
     P = sum(h * w for _, (h, w) in pyr)
     gen = torch.Generator(device=dev).manual_seed(63 + rank)
-    # one clip = the fast window of every FPN level, channels-last, already in the pyramid layout
+    # one clip = the fast window of every FPN level, channels-last
     levels = [torch.randn((1, args.fp, h, w, 256), generator=gen, device=dev, dtype=torch.float32).to(tdt)
               for _, (h, w) in pyr]
-    # bf16: the clip is handed over channel-group-major (64-byte groups), the layout the first convs read fastest
-    clip = PackedClip.from_levels(levels, keys=[k for k, _ in pyr],
-                                  layout='grouped' if (args.precision == 'bf16' and not args.ndhwc_input) else 'ndhwc')
+    grouped = args.precision == 'bf16' and not args.ndhwc_input
+    clip = PackedClip.from_levels(levels, keys=[k for k, _ in pyr], layout='grouped' if grouped else 'ndhwc')
     del levels
+    loss_fn = MSEProxyLoss({k: torch.randn((1, 256, h, w), generator=gen, device=dev) for k, (h, w) in pyr})
 
     timer = model.enable_kernel_timer()
-
-    def step(i):
-        out = model.enhance_packed(clip)
-        loss = proxy_loss(out)
-        if i % 2 == 1:  # model.py:372-374: optimiser every 2nd clip: this backward completes the gradients
-            bucket.arm()
-        loss.backward()
-        if i % 2 == 1:
-            bucket.finish()
-            opt.step()
-            opt.zero_grad()
+    step = make_step(model, opt, bucket, loss_fn, lambda: model.enhance_packed(clip))
 
     for i in range(args.warmup):
         step(i)
@@ -148,13 +198,33 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    kern = timer.summary()  # name -> (calls, mean ms)
+    model._timer = None
+
+    # ---- the same step through the reference's calling convention: lists of fp32 NCHW frames -> layout pass inside
+    dropin_ms = None
+    if not args.no_dropin and world == 1:
+        from collections import OrderedDict
+        fast = OrderedDict((k, torch.randn((args.fp, 256, h, w), generator=gen, device=dev)) for k, (h, w) in pyr)
+        idx = args.fp // 2
+        slow = OrderedDict((k, v[idx - args.sp // 2: idx + (args.sp + 1) // 2]) for k, v in fast.items())
+        dstep = make_step(model, opt, bucket, loss_fn, lambda: model.temporally_enhance_features([slow], [fast]))
+        n = max(2, min(args.steps, 10))
+        for i in range(2):
+            dstep(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n):
+            dstep(i)
+        torch.cuda.synchronize()
+        dropin_ms = 1e3 * (time.perf_counter() - t1) / n
+        del fast, slow
 
     if rank == 0:
         plan = model.plan
-        kern = timer.summary()  # name -> (calls, mean ms)
         # dominant kernel: fast_conv1 forward over the whole 5-level pyramid (72 % of the forward
-        # FLOPs).  It runs as two back-to-back launches of conv3d_kernel<bf16,9,9,TT,1,1,8,1,256>: output frames
-        # 0-15 in blocks of TT=4 and frames 16-21 in blocks of TT=3 (no padded frame); the HIP events bracket both.
+        # FLOPs): ONE launch of conv3d_fs_kernel<bf16, 256> holding the frame blocks of 4, 2 and 1 output frames;
+        # the HIP events (on the stream it is launched on) bracket exactly that launch.
         l = plan.layer('f1')
         dom_flops = 2.0 * l.c_in * l.c_out * l.kt * l.taps * l.t_out * P
         dom = kern.get('conv_fwd/f1')
@@ -162,13 +232,15 @@ def main():
         roofline = None
         if dom:
             ach = dom_flops / (dom[1] * 1e-3) / 1e12
+            headline = (args.sp, args.fp, args.precision) == (4, 32, 'bf16')
             roofline = {'bound': 'mfma',
-                        'kernel': 'sfvos::conv3d_fs_kernel<1,256> (fast_conv1 forward, 256->32 ch, %dx3x3, '
-                                  '%d->%d frames, 5-level pyramid, one launch)' % (l.kt, l.t_in, l.t_out),
+                        'kernel': 'sfvos::conv3d_fs_kernel<%s,256> (fast_conv1 forward, 256->32 ch, %dx3x3, '
+                                  '%d->%d frames, 5-level pyramid, one launch)'
+                                  % ('1' if args.precision == 'bf16' else '0', l.kt, l.t_in, l.t_out),
                         'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                         'launch_ms': round(dom[1], 4), 'flops_per_launch': dom_flops,
-                        'traffic': pmc_traffic(os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json'))
-                        if (args.sp, args.fp, args.precision) == (4, 32, 'bf16') else None}
+                        'traffic': pmc_traffic(os.path.join(ROOT, 'profiles', 'r02_pmc_summary.json'),
+                                               'conv3d_fs_kernel<1, 256>') if headline else None}
         # HBM-bound passes: algorithmic bytes (each tensor touched once per pass) / HIP-event time
         es = 2 if args.precision == 'bf16' else 4
         hbm = {}
@@ -185,28 +257,39 @@ def main():
             for l in plan.layers:
                 k = '%s/%s' % (kind, l.name)
                 if k in kern:
-                    mfma[k] = {'ms': round(kern[k][1], 4), 'TFLOPs': round(fl[l.name] / kern[k][1] / 1e9, 1)}
+                    tf = fl[l.name] / kern[k][1] / 1e9
+                    mfma[k] = {'ms': round(kern[k][1], 4), 'TFLOPs': round(tf, 1), 'frac': round(tf / peak, 3)}
         total_flops = plan.train_flops(P)
         line = {
             'metric': 'clips/sec (T=32, 480x854) fwd+bwd', 'value': round(world * args.steps / dt, 4),
             'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.precision, 'data': 'synthetic',
-            'config': {'workload': 'SlowFastLayers (sp=%d, fp=%d) fwd+bwd+SGD, 1 clip/GPU/step, 5 FPN levels of a '
-                                   '480x854 frame (P=%d), NDHWC inputs resident in HBM' % (args.sp, args.fp, P),
-                       'parallelism': 'dp%d' % world, 'grad_accumulation': 2, 'hip_streams_per_clip': args.streams},
+            'config': {'workload': 'SlowFastLayers (sp=%d, fp=%d) fwd+loss+bwd+SGD, 1 clip/GPU/step, 5 FPN levels of a '
+                                   '480x854 frame (P=%d); input = %s clip resident in HBM (PackedClip hand-over, '
+                                   'no layout pass in the timed region)'
+                                   % (args.sp, args.fp, P, ('channel-group-major [C/32][pos][32] bf16' if grouped else
+                                                            'pyramid NDHWC %s' % args.precision)),
+                       'parallelism': 'dp%d' % world, 'backend': (dist.get_backend() if world > 1 else 'none'),
+                       'grad_accumulation': 2, 'hip_streams_per_clip': args.streams,
+                       'allreduce_buckets': ('per-layer' if args.per_layer_allreduce else 3) if world > 1 else 0},
+            'dropin_api_ms_per_step': None if dropin_ms is None else round(dropin_ms, 3),
+            'dropin_api_note': 'same step through temporally_enhance_features([slow], [fast]) on fp32 NCHW frame lists '
+                               '(reference calling convention, model.py:157-158,340): includes the fp32 NCHW -> '
+                               'bf16 channel-group-major layout pass',
             'tflops_per_clip': round(total_flops / 1e12, 3),
             'achieved_tflops_whole_step': round(total_flops * world * args.steps / dt / 1e12, 2),
             'roofline': roofline,
             'hbm_bound_passes': hbm,
             'mfma_layers': mfma,
-            'kernels_ms': {k: [v[0], round(v[1], 4)] for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:24]},
+            'kernels_ms': {k: [v[0], round(v[1], 4)] for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:28]},
         }
         if not args.no_cpu_baseline and world == 1:
-            line['cpu_baseline'] = cpu_baseline(args.sp, args.fp, args.cpu_threads)
+            line['cpu_baseline'] = cpu_baseline(args.sp, args.fp, args.cpu_threads, args.cpu_clips)
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

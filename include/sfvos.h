@@ -63,7 +63,13 @@ typedef struct sfvos_levels {
   int64_t m[SFVOS_MAX_LEVELS];
 } sfvos_levels;
 
+/* ABI revision: 100 = round 1; 200 = struct_size in sfvos_conv_desc, no `zeros` argument, sfvos_abi_sizes,
+ * sfvos_add_inplace, sfvos_mse_loss / _grad, mask-head entry points. */
 int sfvos_version(void);
+/* sizes[0..n) = sizeof(sfvos_conv_desc), sizeof(sfvos_pyramid), sizeof(sfvos_levels), sizeof(sfvos_mse_table) as THIS
+ * library was compiled; returns how many entries exist (4).  A binder compares them with its own mirrors of the
+ * structs once at load time (a short struct would make the library read strides from whatever follows it). */
+int sfvos_abi_sizes(int* sizes, int n);
 const char* sfvos_last_error(void);
 /* 0 when the current HIP device is a gfx950; SFVOS_E_NODEV otherwise. */
 int sfvos_check_device(void);
@@ -118,7 +124,14 @@ int sfvos_pack_weights_dgrad(const float* w, void* packed, int dtype, int c_out,
  * dst + (c/64)*group_stride + ((t*H+h)*W+w)*64 + c%64; C a multiple of 64. */
 int sfvos_frames_to_groups_fp8(const float* src, int64_t stride_t, int64_t stride_c, int64_t stride_h,
                                int64_t stride_w, void* dst, int T, int C, int H, int W, int64_t group_stride,
-                               float scale, sfvos_stream_t stream);
+                               float scale, int* sat_count, sfvos_stream_t stream);
+/* sat_count (device int, may be NULL): += number of elements with |src * scale| > 448 (they saturate silently in
+ * e4m3; FPN features are unbounded conv outputs, so a fixed scale must be checked against the data). */
+
+/* *amax (device float holding a non-negative value, e.g. 0) = max(*amax, max |src|) over the strided fp32 frames:
+ * calibration of the e4m3 activation scale (scale = 448 / amax with head-room).  Order-independent, deterministic. */
+int sfvos_frames_absmax(const float* src, int64_t stride_t, int64_t stride_c, int64_t stride_h, int64_t stride_w,
+                        int T, int C, int H, int W, float* amax, sfvos_stream_t stream);
 
 /* conv weight fp32 [c_out][c_in][kt][kh][kw] -> e4m3 forward image for sfvos_conv3d (dtype SFVOS_FP8), quantised per
  * output channel: weight_scale[n] = 448 / max|w[n]|.  bias_descale: [3][c_out] floats: row 0 = bias (zeros when bias is
@@ -130,6 +143,7 @@ int sfvos_pack_weights_fp8(const float* w, const float* bias, void* packed, floa
 /* ---- convolution (replaces aten::convolution at model.py:112,120,124,132,136,144,147) ---- */
 
 typedef struct sfvos_conv_desc {
+  int struct_size; /* = sizeof(sfvos_conv_desc) of the binder's mirror; every entry point taking a desc rejects a mismatch */
   int dtype;       /* SFVOS_F32: f32 storage, exact-f32 MFMA; SFVOS_BF16: bf16 storage, f32 accumulate;
                     * SFVOS_FP8 (sfvos_conv3d only, 3x3 layers with c_out <= 32): x and the weight image are OCP e4m3
                     * (x in 64-channel = 64-byte groups: x_group_stride > 0 counted in elements = bytes, or plain NDHWC
@@ -138,9 +152,12 @@ typedef struct sfvos_conv_desc {
                     * the per-output-channel de-quantisation factor 1/(activation scale * weight scale[n])
                     * (sfvos_pack_weights_fp8 writes both rows): y = acc * row1 + row0 */
   int batch;       /* clips B */
-  int t_in;        /* input frames the conv sees */
-  int t_alloc;     /* frames per clip the x BUFFER holds (>= t_offset + t_in): lets the slow pathway   */
-  int t_offset;    /* read its centre frames (model.py:242-248) straight out of the fast clip's buffer */
+  int t_in;        /* input frames the conv sees: its window is frames [t_offset, t_offset + t_in) of the x buffer */
+  int t_alloc;     /* frames per clip the x BUFFER holds.  Lets the slow pathway read its centre frames            */
+  int t_offset;    /* (model.py:242-248) straight out of the fast clip's buffer.  Level-major x only: the window may
+                    * stick out of [0, t_alloc) on either side (t_offset < 0, or t_offset + t_in > t_alloc); those
+                    * frames are ZERO frames that are never read -- the reference's zero feature padding beyond the
+                    * ends of a sequence (model.py:215-225) without materialising zeros */
   int c_in, c_out; /* multiples of 32 */
   int kt;          /* temporal taps */
   int taps;        /* 9 = 3x3 spatial, zero pad 1 ; 1 = 1x1 spatial, no pad */
@@ -168,10 +185,10 @@ int sfvos_conv3d_stat_rows(const sfvos_conv_desc* d, int* rows_per_level);
 /* y (=|+=) bias + sum_{dt,dh,dw,c} x[l][b][t_offset+t+dt-pad_t][h+dh-1][w+dw-1][c] * W over every level.
  * x: pyramid buffer with t_alloc frames; y: pyramid buffer with t_out = t_in + 2*pad_t - kt + 1 frames.
  * bias may be NULL.  stat_part may be NULL; otherwise it receives per-tile partial (sum, sum of
- * squares) of the values written.  `zeros`: caller-provided zero-filled device buffer >= 256 B (must be non-NULL;
- * kept for ABI stability -- the kernels now zero-fill padding through the buffer descriptors' range check). */
+ * squares) of the values written.  Spatial / temporal zero padding is produced by the buffer descriptors' range
+ * check (frames outside [0, t_in) and pixels outside the image are never read). */
 int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
-                 float* stat_part, const void* zeros, sfvos_stream_t stream);
+                 float* stat_part, sfvos_stream_t stream);
 
 /* ---- weight gradient (aten::convolution_backward grad_weight / grad_bias) -------------- */
 
@@ -183,7 +200,7 @@ size_t sfvos_conv3d_wgrad_workspace_bytes(const sfvos_conv_desc* d);
  * dy the gradient w.r.t. the conv output (pyramid buffer with t_out frames, ld_y).
  * accumulate != 0 adds into grad_w (model.py:369-374 accumulates two clips before stepping). */
 int sfvos_conv3d_wgrad(const sfvos_conv_desc* d, const void* x, const void* dy, float* grad_w, int accumulate,
-                       void* workspace, const void* zeros, sfvos_stream_t stream);
+                       void* workspace, sfvos_stream_t stream);
 
 /* ---- batch norm (aten::native_batch_norm / _backward at model.py:113,121,...,148) -------
  * Per-level coefficient tables: quantity q of level l lives at q_ptr + l*coef_stride (elements). */
@@ -244,6 +261,31 @@ int sfvos_sgd_step(float* p, const float* g, float* momentum_buf, int64_t n, flo
 
 /* x[i] *= s  (gradient averaging after the data-parallel all-reduce). */
 int sfvos_scale(float* x, int64_t n, float s, sfvos_stream_t stream);
+
+/* dst[i] += src[i] over n elements of `dtype` (n a multiple of 8): gradient fan-in where two consumers read the same
+ * frames -- the slow pathway's window of the input clip (model.py:242-248: its gradient adds into frames
+ * [k, k+sp) of the fast clip's gradient). */
+int sfvos_add_inplace(void* dst, const void* src, int dtype, int64_t n, sfvos_stream_t stream);
+
+/* ---- stand-in training loss (bench / tests) ---------------------------------------------------
+ * The reference's loss is the sum of torchvision's RoI-head losses (model.py:346-368; torchvision is absent here and
+ * out of scope); the benchmark and the parity fixtures use  loss = sum_l mean((out_l - target_l)^2)  over the fused
+ * maps out_l [B,256,H_l,W_l] fp32 (oracle/slowfast_ref.py proxy_loss).  Two launches: value, gradient. */
+typedef struct sfvos_mse_table {
+  int n;                                   /* tensors (FPN levels), 1..SFVOS_MAX_LEVELS */
+  const float* out[SFVOS_MAX_LEVELS];      /* contiguous fp32, numel[l] elements */
+  const float* target[SFVOS_MAX_LEVELS];
+  float* grad[SFVOS_MAX_LEVELS];           /* written by sfvos_mse_loss_grad only (may be NULL for sfvos_mse_loss) */
+  int64_t numel[SFVOS_MAX_LEVELS];
+} sfvos_mse_table;
+
+/* fp32 partial rows sfvos_mse_loss needs in `part` for this table. */
+int sfvos_mse_loss_rows(const sfvos_mse_table* t);
+/* loss[0] = sum_l (1/numel_l) sum_i (out_l[i] - target_l[i])^2, reduced in a fixed order (f64 accumulate). */
+int sfvos_mse_loss(const sfvos_mse_table* t, float* part, float* loss, sfvos_stream_t stream);
+/* grad_l[i] = upstream * 2 (out_l[i] - target_l[i]) / numel_l; upstream: device scalar (autograd's grad_output) or
+ * NULL for 1. */
+int sfvos_mse_loss_grad(const sfvos_mse_table* t, const float* upstream, sfvos_stream_t stream);
 
 /* ---- evaluation-side reducer (reference code/helpers/davis_evaluate.py:40-42) ------------ */
 

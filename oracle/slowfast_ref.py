@@ -56,6 +56,9 @@ class OracleSlowFastLayers(nn.Module):
         l1, so1, fo1 = lateral_kernel_size(slow_pathway_size, ks[0], fast_pathway_size, kf[0])
         l2, _, _ = lateral_kernel_size(so1, ks[1], fo1, kf[1])
         self.kernel_sizes = {'slow': ks, 'fast': kf, 'lateral': (l1, l2)}
+        # tests may set this to a list: every ReLU then appends min |input| (how far the clip is from a mask flip
+        # between two correct implementations -- the ReLU derivative is discontinuous at 0)
+        self.relu_margins = None
         kt = {'fast_conv1': kf[0], 'slow_conv1': ks[0], 'fast_conv2': kf[1], 'slow_conv2': ks[1],
               'fast_conv3': kf[2], 'slow_conv3': ks[2]}
         for conv, bn, cin, cout in _MAIN:
@@ -75,6 +78,8 @@ class OracleSlowFastLayers(nn.Module):
             b.num_batches_tracked += 1
         y = F.batch_norm(y, b.running_mean, b.running_var, b.weight, b.bias,
                          training=self.training, momentum=0.1, eps=1e-5)
+        if relu and self.relu_margins is not None:
+            self.relu_margins.append(float(y.detach().abs().min()))
         return F.relu(y) if relu else y
 
     def forward(self, slow, fast):

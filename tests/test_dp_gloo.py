@@ -110,3 +110,49 @@ def test_grad_bucket_segments_overlap_api_world2():
     for rank, _, reduced, refused in got:
         assert refused
         assert torch.allclose(torch.from_numpy(reduced), want, atol=1e-6)
+
+
+def _worker_buckets(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from sfvos_amd import GradBucket, init_distributed
+    init_distributed('gloo')
+    n = 4096
+    flat = torch.randn(n, generator=torch.Generator().manual_seed(70 + rank))
+    local = flat.clone()
+    bucket = GradBucket(flat)
+    bucket.set_buckets([(2000, 4096), (500, 2000)])       # [0, 500) belongs to no bucket
+    bucket.arm()
+    launched = []
+    for lo, hi in ((3000, 4096), (500, 1200), (2000, 3000), (0, 300), (1200, 2000)):
+        bucket.segment_ready(lo, hi)
+        launched.append(sorted(bucket._sent))
+    bucket.finish()
+    # finish() with nothing armed or started must still reduce (never scale unreduced gradients)
+    flat2 = torch.randn(n, generator=torch.Generator().manual_seed(90 + rank))
+    local2 = flat2.clone()
+    GradBucket(flat2).finish()
+    q.put((rank, local.numpy(), flat.clone().numpy(), launched, local2.numpy(), flat2.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_bucket_coalesced_buckets_world2():
+    """Segments inside a bucket are held back until they cover it and then go out as ONE collective; segments outside
+    every bucket go at once; finish() sends the rest.  Result = plain average, as for one whole-buffer all-reduce."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_buckets, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    want = sum(torch.from_numpy(g[1]) for g in got) / world
+    want2 = sum(torch.from_numpy(g[4]) for g in got) / world
+    for rank, _, reduced, launched, _, reduced2 in got:
+        assert launched == [[], [], [(2000, 4096)], [(0, 300), (2000, 4096)], [(0, 300), (500, 2000), (2000, 4096)]]
+        assert torch.allclose(torch.from_numpy(reduced), want, atol=1e-6)
+        assert torch.allclose(torch.from_numpy(reduced2), want2, atol=1e-6)

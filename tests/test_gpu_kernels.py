@@ -105,8 +105,7 @@ def test_conv3d_forward_bias_stats(lib, prec, case):
     rows = lib.load().sfvos_conv3d_stat_rows(ctypes.byref(d), rows_pl)
     assert rows > 0 and sum(rows_pl[:len(shapes)]) == rows
     part = torch.full((rows, 2, cout), 1e9, dtype=torch.float32, device='cuda')
-    zeros = torch.zeros(1024, dtype=torch.uint8, device='cuda')
-    lib.call('sfvos_conv3d', ctypes.byref(d), P(xd), P(wp), P(bias.cuda()), P(y), P(part), P(zeros), S())
+    lib.call('sfvos_conv3d', ctypes.byref(d), P(xd), P(wp), P(bias.cuda()), P(y), P(part), S())
     torch.cuda.synchronize()
     got = from_pyr(y, B, cout, t_out, shapes)
     r0 = 0
@@ -135,8 +134,7 @@ def test_conv3d_reads_a_frame_window_of_a_longer_clip(lib, prec):
     wp = torch.empty(w.numel(), dtype=TDT[prec], device='cuda')
     lib.call('sfvos_pack_weights_fwd', P(w.cuda()), P(wp), d.dtype, cout, cin, kt, 9, S())
     y = torch.empty((sum(B * t_out * H * W for H, W in shapes), cout), dtype=TDT[prec], device='cuda')
-    zeros = torch.zeros(1024, dtype=torch.uint8, device='cuda')
-    lib.call('sfvos_conv3d', ctypes.byref(d), P(xd), P(wp), None, P(y), None, P(zeros), S())
+    lib.call('sfvos_conv3d', ctypes.byref(d), P(xd), P(wp), None, P(y), None, S())
     for a, b in zip(from_pyr(y, B, cout, t_out, shapes), refs):
         assert relmax(a, b) < TOL[prec]
     # weight gradient through the same window
@@ -149,7 +147,51 @@ def test_conv3d_reads_a_frame_window_of_a_longer_clip(lib, prec):
     dyd = to_pyr(dys, prec)
     ws = torch.empty(lib.load().sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d)), dtype=torch.uint8, device='cuda')
     gw = torch.empty(w.shape, dtype=torch.float32, device='cuda')
-    lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(xd), P(dyd), P(gw), 0, P(ws), P(zeros), S())
+    lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(xd), P(dyd), P(gw), 0, P(ws), S())
+    assert relmax(gw.cpu(), wz.grad) < TOL[prec]
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('case', [(2, 7, 4, -2, [(6, 10), (3, 7)], 64, 32, 3),      # 2 zero frames in front, 1 behind
+                                  (1, 5, 3, 1, [(9, 17)], 256, 192, 2),             # window [1, 6) of a 3-frame buffer
+                                  (1, 9, 5, -1, [(12, 21), (5, 9)], 256, 32, 3)])   # frame-split kernel
+def test_conv3d_window_beyond_the_buffer_reads_zero_frames(lib, prec, case):
+    """t_offset < 0 or t_offset + t_in > t_alloc: the frames of the window that the buffer does not hold are zero
+    frames (model.py:215-225 pads windows beyond the ends of a sequence with zero features) that are never read --
+    forward conv and weight gradient against F.conv3d on explicitly zero-padded clips."""
+    B, t_in, t_alloc, t_off, shapes, cin, cout, kt = case
+    g = torch.Generator().manual_seed(17)
+    w = torch.randn(cout, cin, kt, 3, 3, generator=g) / np.sqrt(cin * kt * 9)
+    xs = [torch.randn(B, cin, t_alloc, H, W, generator=g) for (H, W) in shapes]
+    if prec == 'bf16':
+        xs, w = [x.bfloat16().float() for x in xs], w.bfloat16().float()
+
+    def window(x):
+        full = torch.zeros(B, cin, t_in, x.shape[3], x.shape[4])
+        for t in range(t_in):
+            if 0 <= t_off + t < t_alloc:
+                full[:, :, t] = x[:, :, t_off + t]
+        return full
+    wins = [window(x) for x in xs]
+    refs = [F.conv3d(v, w, None, padding=(0, 1, 1)) for v in wins]
+    xd = to_pyr(xs, prec)
+    d, t_out = make_desc(lib, prec, B, t_in, shapes, cin, cout, kt, 9, 0, cin, cout, t_alloc=t_alloc, t_offset=t_off)
+    wp = torch.empty(w.numel(), dtype=TDT[prec], device='cuda')
+    lib.call('sfvos_pack_weights_fwd', P(w.cuda()), P(wp), d.dtype, cout, cin, kt, 9, S())
+    y = torch.empty((sum(B * t_out * H * W for H, W in shapes), cout), dtype=TDT[prec], device='cuda')
+    lib.call('sfvos_conv3d', ctypes.byref(d), P(xd), P(wp), None, P(y), None, S())
+    for a, b in zip(from_pyr(y, B, cout, t_out, shapes), refs):
+        assert relmax(a, b) < TOL[prec]
+    dys = [torch.randn(B, cout, t_out, H, W, generator=g) for (H, W) in shapes]
+    if prec == 'bf16':
+        dys = [v.bfloat16().float() for v in dys]
+    wz = torch.zeros_like(w, requires_grad=True)
+    for v, dy in zip(wins, dys):
+        F.conv3d(v, wz, None, padding=(0, 1, 1)).backward(dy)
+    dyd = to_pyr(dys, prec)
+    ws = torch.empty(lib.load().sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d)), dtype=torch.uint8, device='cuda')
+    gw = torch.empty(w.shape, dtype=torch.float32, device='cuda')
+    lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(xd), P(dyd), P(gw), 0, P(ws), S())
     assert relmax(gw.cpu(), wz.grad) < TOL[prec]
 
 
@@ -178,12 +220,11 @@ def test_conv3d_dgrad_and_accumulate(lib, prec, case):
     wp = torch.empty(w.numel(), dtype=TDT[prec], device='cuda')
     lib.call('sfvos_pack_weights_dgrad', P(w.cuda()), P(wp), d.dtype, cout, cin, kt, taps, S())
     dx = torch.empty((sum(B * T * H * W for H, W in shapes), cin), dtype=TDT[prec], device='cuda')
-    zeros = torch.zeros(1024, dtype=torch.uint8, device='cuda')
-    lib.call('sfvos_conv3d', ctypes.byref(d), P(dyd), P(wp), None, P(dx), None, P(zeros), S())
+    lib.call('sfvos_conv3d', ctypes.byref(d), P(dyd), P(wp), None, P(dx), None, S())
     for a, x in zip(from_pyr(dx, B, cin, T, shapes), xs):
         assert relmax(a, x.grad) < TOL[prec]
     d.accumulate = 1  # second call adds: dx == 2 * grad
-    lib.call('sfvos_conv3d', ctypes.byref(d), P(dyd), P(wp), None, P(dx), None, P(zeros), S())
+    lib.call('sfvos_conv3d', ctypes.byref(d), P(dyd), P(wp), None, P(dx), None, S())
     for a, x in zip(from_pyr(dx, B, cin, T, shapes), xs):
         assert relmax(a, 2 * x.grad) < 2 * TOL[prec]
 
@@ -223,13 +264,12 @@ def test_grouped_input_layout_is_bit_identical(lib, case):
         lib.call('sfvos_pack_weights_fwd', P(w.cuda()), P(wp), d.dtype, cout, cin, kt, taps, S())
         Mo = sum(B * t_out * H * W for H, W in shapes)
         y = torch.zeros((Mo, cout), dtype=torch.bfloat16, device='cuda')
-        zeros = torch.zeros(1024, dtype=torch.uint8, device='cuda')
-        lib.call('sfvos_conv3d', ctypes.byref(d), P(x), P(wp), None, P(y), None, P(zeros), S())
+        lib.call('sfvos_conv3d', ctypes.byref(d), P(x), P(wp), None, P(y), None, S())
         outs.append(y)
         dy = (torch.randn(Mo, cout, generator=torch.Generator().manual_seed(5)) * 0.1).bfloat16().cuda()
         ws = torch.empty(lib.load().sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d)), dtype=torch.uint8, device='cuda')
         gw = torch.empty(w.shape, dtype=torch.float32, device='cuda')
-        lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(x), P(dy), P(gw), 0, P(ws), P(zeros), S())
+        lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(x), P(dy), P(gw), 0, P(ws), S())
         grads.append(gw)
     torch.cuda.synchronize()
     assert float(outs[0].float().abs().max()) > 0.1
@@ -272,11 +312,77 @@ def test_conv3d_wgrad(lib, prec, case):
     assert nbytes > 0
     ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
     gw = torch.full(ref.shape, 5.0, dtype=torch.float32, device='cuda')
-    zeros = torch.zeros(1024, dtype=torch.uint8, device='cuda')
-    lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(xd), P(dyd), P(gw), 0, P(ws), P(zeros), S())
+    lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(xd), P(dyd), P(gw), 0, P(ws), S())
     assert relmax(gw.cpu(), ref) < TOL[prec]
-    lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(xd), P(dyd), P(gw), 1, P(ws), P(zeros), S())
+    lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(xd), P(dyd), P(gw), 1, P(ws), S())
     assert relmax(gw.cpu(), 2 * ref) < 2 * TOL[prec]
+
+
+# Pyramids with more pixel tiles than the split-K count make_wgrad_plan picks: every workgroup sweeps SEVERAL tiles, so
+# the x-ring prefetch across tile (and level) boundaries, the `q0 += dt_live - 1` frame wrap and the `xi_q <= need`
+# reload path of wgrad_kernel run -- the configuration of the benchmark (700+ tiles, 2-12 per workgroup).
+WGRAD_MULTI_TILE_CASES = [
+    (1, 13, [(96, 168), (24, 42)], 256, 32, 11, 9),   # cfg (1,2,4): fast_conv1's shape, kt 11 = 4 + 4 + 3 taps
+    (1, 3, [(96, 168), (12, 21)], 256, 192, 2, 9),    # cfg (2,2,2): slow_conv1/2's shape
+    (1, 14, [(96, 168)], 32, 32, 11, 9),              # cfg (1,1,8): fast_conv2's shape, t_out 4
+    (1, 22, [(96, 168), (5, 9)], 32, 64, 20, 1),      # cfg (2,1,4): the first lateral, kt 20
+]
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('case', WGRAD_MULTI_TILE_CASES)
+def test_conv3d_wgrad_several_tiles_per_workgroup(lib, prec, case):
+    B, T, shapes, cin, cout, kt, taps = case
+    g = torch.Generator().manual_seed(11)
+    k = 3 if taps == 9 else 1
+    w = torch.zeros(cout, cin, kt, k, k, requires_grad=True)
+    t_out = T - kt + 1
+    xs = [torch.randn(B, cin, T, H, W, generator=g) for (H, W) in shapes]
+    dys = [torch.randn(B, cout, t_out, H, W, generator=g) for (H, W) in shapes]
+    if prec == 'bf16':
+        xs, dys = [v.bfloat16().float() for v in xs], [v.bfloat16().float() for v in dys]
+    for x, dy in zip(xs, dys):
+        F.conv3d(x, w, None, padding=(0, 1, 1) if taps == 9 else 0).backward(dy)
+    ref = w.grad
+    xd, dyd = to_pyr(xs, prec), to_pyr(dys, prec)
+    d, _ = make_desc(lib, prec, B, T, shapes, cin, cout, kt, taps, 0, cin, cout)
+    nbytes = lib.load().sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
+    psplit = nbytes // (4 * ref.numel())
+    th = 4 if prec == 'fp32' else 8
+    ntiles = sum(B * -(-H // th) * -(-W // 16) for H, W in shapes)
+    per = -(-ntiles // psplit)
+    assert per >= 2, 'case does not sweep several tiles per workgroup (ntiles %d, split %d)' % (ntiles, psplit)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    gw = torch.full(ref.shape, 5.0, dtype=torch.float32, device='cuda')
+    lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(xd), P(dyd), P(gw), 0, P(ws), S())
+    e = relmax(gw.cpu(), ref)
+    print('wgrad %s %s: %d tiles, split %d, %d tiles per workgroup, max err / scale %.2e' % (case, prec, ntiles, psplit, per, e))
+    assert e < TOL[prec]
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_add_inplace_and_mse_loss(lib, prec):
+    """sfvos_add_inplace (gradient fan-in of the slow window) and the stand-in loss (value + gradient) against torch."""
+    g = torch.Generator().manual_seed(21)
+    a, b = torch.randn(5 * 1024 + 8, generator=g), torch.randn(5 * 1024 + 8, generator=g)
+    ad, bd = a.to(TDT[prec]).cuda(), b.to(TDT[prec]).cuda()
+    want = (ad.float() + bd.float()).to(TDT[prec])
+    lib.call('sfvos_add_inplace', P(ad), P(bd), lib.F32 if prec == 'fp32' else lib.BF16, ad.numel(), S())
+    assert torch.equal(ad, want)
+    if prec == 'bf16':
+        return
+    from sfvos_amd import MSEProxyLoss
+    shapes = [(1, 256, 12, 21), (1, 256, 6, 10), (2, 8, 3, 5)]
+    outs = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    tgts = {str(i): torch.randn(s, generator=g).cuda() for i, s in enumerate(shapes)}
+    loss = MSEProxyLoss(tgts)({str(i): o for i, o in enumerate(outs)})
+    ref_in = [o.detach().cpu().double().requires_grad_(True) for o in outs]
+    ref = sum(((o - tgts[str(i)].cpu().double()) ** 2).mean() for i, o in enumerate(ref_in))
+    assert abs(loss.item() - ref.item()) < 1e-6 * abs(ref.item())
+    (loss * 3.0).backward()
+    (ref * 3.0).backward()
+    for o, r in zip(outs, ref_in):
+        assert relmax(o.grad.cpu(), r.grad) < 1e-6
 
 
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
@@ -401,7 +507,10 @@ def test_bad_arguments_report_errors(lib):
     d, _ = make_desc(lib, 'fp32', 1, 4, [(8, 8)], 48, 32, 2, 9, 0, 48, 32)  # c_in not a multiple of 32
     assert lib.load().sfvos_conv3d_stat_rows(ctypes.byref(d), None) < 0
     assert b'multiples of 32' in lib.load().sfvos_last_error()
-    d, _ = make_desc(lib, 'fp32', 1, 4, [(8, 8)], 64, 32, 2, 9, 0, 64, 32, t_alloc=3)  # window outside the buffer
+    d, _ = make_desc(lib, 'fp32', 1, 4, [(8, 8)], 64, 32, 2, 9, 0, 64, 32, t_alloc=3)  # window outside a frame RING
+    d.x_frame_stride = 64
+    assert lib.load().sfvos_conv3d_stat_rows(ctypes.byref(d), None) < 0
+    d, _ = make_desc(lib, 'fp32', 1, 4, [(8, 8)], 64, 32, 2, 9, 0, 64, 32, t_alloc=0)
     assert lib.load().sfvos_conv3d_stat_rows(ctypes.byref(d), None) < 0
     with pytest.raises(RuntimeError):
         lib.call('sfvos_scale', None, 10, 1.0, S())
@@ -447,7 +556,7 @@ def test_conv3d_fp8_operands_match_a_dequantised_reference(lib, case):
         for b in range(B):
             s = xc[b]
             lib.call('sfvos_frames_to_groups_fp8', P(s), s.stride(1), s.stride(0), s.stride(2), s.stride(3),
-                     P(x_gr, (off + b * T * H * W) * 64), T, cin, H, W, M * 64, act_scale, S())
+                     P(x_gr, (off + b * T * H * W) * 64), T, cin, H, W, M * 64, act_scale, None, S())
         off += B * T * H * W
     wp = torch.empty(w.numel(), dtype=torch.uint8, device='cuda')
     bd = torch.empty((3, cout), dtype=torch.float32, device='cuda')
@@ -460,8 +569,7 @@ def test_conv3d_fp8_operands_match_a_dequantised_reference(lib, case):
     y = torch.zeros((Mo, cout), dtype=torch.bfloat16, device='cuda')
     rows = lib.load().sfvos_conv3d_stat_rows(ctypes.byref(d), None)
     part = torch.zeros((rows, 2, cout), dtype=torch.float32, device='cuda')
-    zeros = torch.zeros(1024, dtype=torch.uint8, device='cuda')
-    lib.call('sfvos_conv3d', ctypes.byref(d), P(x_gr), P(wp), P(bd), P(y), P(part), P(zeros), S())
+    lib.call('sfvos_conv3d', ctypes.byref(d), P(x_gr), P(wp), P(bd), P(y), P(part), S())
     torch.cuda.synchronize()
     # reference on the same quantised operands
     f8 = torch.float8_e4m3fn

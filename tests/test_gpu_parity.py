@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from golden_util import (BIG_LEVELS, CONFIGS, SMALL_LEVELS, clip_inputs, load_case, max_rel_err, rel_err, sample_idx)
-from oracle.closed_form import closed_form_state_dict
+from oracle.closed_form import closed_form_features, closed_form_state_dict
 from oracle.slowfast_ref import OracleSlowFastLayers, proxy_loss
 
 pytestmark = pytest.mark.gpu
@@ -189,10 +189,12 @@ def test_cpu_tensors_are_refused():
         m(torch.zeros(1, 256, 1, 4, 4), torch.zeros(1, 256, 1, 4, 4))
 
 
-@pytest.mark.parametrize('sp,fp', [(3, 7), (4, 32)])
+@pytest.mark.parametrize('sp,fp', [(3, 7), (4, 32), (4, 64)])
 def test_bf16_path_error_is_bounded(sp, fp):
-    """bf16 storage / f32 accumulate: error vs the fp32 fixtures is measured here and bounded at 5e-2 of
-    the output scale; argmax agreement is reported, not required."""
+    """bf16 storage / f32 accumulate (the dtype the headline number is quoted in), forward AND backward against the
+    fp32 fixtures generated from the reference's class: errors are measured and printed; bounds (stated here): fused
+    maps 5e-2 of the output scale, loss 2e-2, every parameter gradient within 5e-2 of its scale (norm and the 64 samples;
+    measured 0.5-2e-2).  Argmax agreement is reported, not required."""
     g = load_case(sp, fp, 'small')
     m, dev = build(sp, fp, 'bf16')
     m.train()
@@ -208,63 +210,283 @@ def test_bf16_path_error_is_bounded(sp, fp):
               % (sp, fp, k, e, rel_err(v.detach().cpu().numpy(), ref), agree))
         assert e < 5e-2
     assert abs(loss.item() - float(g['loss/0'])) < 2e-2 * abs(float(g['loss/0']))
+    # gradients of the first clip alone: the fixture holds them for the sum of two clips, so run the second one too
+    slow, fast = clip_inputs(sp, fp, SMALL_LEVELS, 1, dev, clips=g['clips'])
+    proxy_loss(m.temporally_enhance_features(slow, fast)).backward()
+    gscale = max(float(g['gnorm/%s' % k]) for k, _ in m.named_parameters())
+    rows = []
+    for key, p in m.named_parameters():
+        gr = p.grad.detach().reshape(-1).cpu()
+        ref_n, ref_s = float(g['gnorm/%s' % key]), g['gsamp/%s' % key]
+        if key.endswith('conv1.bias') or key.endswith('conv2.bias') or key.endswith('conv3.bias'):
+            assert float(gr.double().norm()) < 2e-2 * gscale   # true gradient 0 (bias in front of train-mode BN)
+            continue
+        got_s = gr[sample_idx(gr.numel())].numpy()
+        rows.append((key, abs(float(gr.double().norm()) - ref_n) / ref_n, rel_err(got_s, ref_s),
+                     float(np.abs(got_s - ref_s).max() / np.abs(ref_s).max())))
+    for key, en, el2, emax in rows:
+        print('bf16 (%d,%d) grad %-18s norm err %.2e, samples rel-L2 %.2e, max / scale %.2e' % (sp, fp, key, en, el2, emax))
+    # bounds (stated): gradient norms within 5e-2; the 64 sampled entries within 0.15 rel-L2 (the first-layer weight
+    # gradients are heavily cancelling sums -- dx is orthogonal to 1 and to x-hat per channel -- which amplifies the
+    # bf16 rounding of dx and x: measured 0.5-12e-2 per entry at 312 positions, 1e-3 on the norms)
+    for key, en, el2, emax in rows:
+        assert en < 5e-2 and el2 < 0.15, (key, en, el2, emax)
 
 
-def test_full_size_properties_headline_config():
-    """(sp,fp)=(4,32) on a pyramid of DAVIS levels '1','3','pool' (96x168, 24x42, 12x21) handed over as a
-    PackedClip, bf16: determinism (no atomics anywhere), train-mode BN invariants of the fused map per level
-    (per-channel mean == beta, std == |gamma|), and agreement with the fp32 path."""
-    from sfvos_amd import PackedClip
-    torch.manual_seed(0)
-    shapes = [(96, 168), (24, 42), (12, 21)]
-    m, dev = build(4, 32, 'bf16')
+# ---- parity at the BENCHMARKED size, dtype and path (bench.py: (4,32), the 5-level DAVIS pyramid incl. level '0',
+# PackedClip hand-over, FusedSGD.attach gradient sink, overwrite + accumulate) against the CPU oracle run on this
+# box's host cores (model.py:118-165,369-374) -----------------------------------------------------------------
+@pytest.fixture(scope='module')
+def full_size_oracle():
+    from sfvos_amd import davis_pyramid
+    from oracle.slowfast_ref import _target
+    sp, fp = 4, 32
+    pyr = davis_pyramid()
+    gen = torch.Generator().manual_seed(63)
+    # bf16-representable values, so the fp32 and the bf16 run (and the oracle) see the very same clip
+    fast = OrderedDict((k, torch.randn(fp, 256, h, w, generator=gen).bfloat16().float()) for k, (h, w) in pyr)
+    idx = fp // 2
+    slow = OrderedDict((k, v[idx - sp // 2: idx + (sp + 1) // 2]) for k, v in fast.items())
+    o = OracleSlowFastLayers(256, torch.device('cpu'), sp, fp)
+    o.load_state_dict(closed_form_state_dict(o))
+    o.train()
+    opt = torch.optim.SGD(o.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    out = o.temporally_enhance_features([slow], [fast])
+    loss = proxy_loss(out)
+    loss.backward()
+    res = dict(sp=sp, fp=fp, pyr=pyr, fast=fast, loss=float(loss),
+               out={k: v.detach().clone() for k, v in out.items()},
+               grad={k: p.grad.detach().clone() for k, p in o.named_parameters()},
+               target={k: _target(k, tuple(v.shape), v.device) for k, v in out.items()})
+    del out, loss
+    # the module under test runs the SAME clip twice (overwrite, then accumulate into the gradient sink, as bench.py's
+    # two clips per optimiser step): gradients are exactly 2x, the running statistics see two updates per level
+    with torch.no_grad():
+        o.temporally_enhance_features([slow], [fast])
+        for p in o.parameters():
+            p.grad.mul_(2.0)
+    res['stat'] = {k: b.detach().clone() for k, b in o.named_buffers()}
+    opt.step()
+    res['param'] = {k: p.detach().clone() for k, p in o.named_parameters()}
+    return res
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_full_size_headline_config_matches_the_oracle(full_size_oracle, precision):
+    """fp32: fused maps, loss, BN running statistics, EVERY parameter gradient (whole tensors) and the parameters after
+    the SGD step within 1e-3 of the oracle (tensor scale); per-pixel argmax over the 256 fused channels identical at
+    every pixel whose top-2 margin in the oracle exceeds fp32 round-off (1e-4 of the map's scale; the pixels below
+    that margin are counted and printed -- at 85 932 pixels a handful of exact near-ties exist).
+    bf16 (the bench dtype, channel-group-major clip): the same quantities, errors measured and printed, bounded at
+    5e-2 (outputs, gradients), 2e-2 (loss); argmax agreement reported."""
+    from sfvos_amd import FusedSGD, MSEProxyLoss, PackedClip
+    r = full_size_oracle
+    sp, fp, pyr = r['sp'], r['fp'], r['pyr']
+    m, dev = build(sp, fp, precision)
     m.train()
-    g = torch.Generator(device='cuda').manual_seed(63)
-    levels = [torch.randn(1, 32, H, W, 256, generator=g, device=dev, dtype=torch.float32) for (H, W) in shapes]
-    clip = PackedClip.from_levels([x.to(torch.bfloat16) for x in levels], keys=['1', '3', 'pool'])
-    with torch.no_grad():
-        a = m.enhance_packed(clip)
-        b = m.enhance_packed(clip)
-    assert list(a.keys()) == ['1', '3', 'pool']
-    m32, _ = build(4, 32, 'fp32')
-    m32.train()
-    with torch.no_grad():
-        c = m32.enhance_packed(PackedClip.from_levels([x.to(torch.bfloat16).float() for x in levels],
-                                                      keys=['1', '3', 'pool']))
-    beta = torch.cat([m.bn_s3.bias, m.bn_f3.bias]).detach().double().cpu()
-    gamma = torch.cat([m.bn_s3.weight, m.bn_f3.weight]).detach().double().cpu()
-    for k, (H, W) in zip(a.keys(), shapes):
-        assert tuple(a[k].shape) == (1, 256, H, W)
-        assert torch.equal(a[k], b[k]), 'two runs differ: the path must be deterministic'
-        mean = a[k].double().mean((0, 2, 3)).cpu()
-        var = a[k].double().var((0, 2, 3), unbiased=False).cpu()
-        assert float((mean - beta).abs().max()) < 2e-2
-        assert float((var.sqrt() - gamma.abs()).abs().max()) < 2e-2
-        assert max_rel_err(a[k].cpu().numpy(), c[k].cpu().numpy()) < 5e-2
+    opt = FusedSGD(m.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4).attach(m)
+    tdt = torch.bfloat16 if precision == 'bf16' else torch.float32
+    levels = [r['fast'][k].to(dev).permute(0, 2, 3, 1).unsqueeze(0).to(tdt).contiguous() for k, _ in pyr]
+    clip = PackedClip.from_levels(levels, keys=[k for k, _ in pyr],
+                                  layout='grouped' if precision == 'bf16' else 'ndhwc')
+    del levels
+    loss_fn = MSEProxyLoss({k: v.to(dev) for k, v in r['target'].items()})
+    opt.zero_grad()
+    out = m.enhance_packed(clip)
+    loss = loss_fn(out)
+    loss.backward()                      # overwrite mode of the gradient sink
+    loss_fn(m.enhance_packed(clip)).backward()   # accumulate mode
+    assert m._grad_sink is opt
+    tol = FP32_TOL if precision == 'fp32' else 5e-2
+    for k, v in out.items():
+        ref = r['out'][k]
+        got = v.detach().cpu()
+        e = max_rel_err(got.numpy(), ref.numpy())
+        top2 = ref.topk(2, dim=1).values
+        margin = (top2[:, 0] - top2[:, 1])
+        safe = margin > 1e-4 * float(ref.abs().max())
+        same = got.argmax(1) == ref.argmax(1)
+        print('%s full size level %s: max err / scale %.3e, rel-L2 %.3e, argmax agreement %.6f, %d of %d pixels inside '
+              'the round-off margin' % (precision, k, e, rel_err(got.numpy(), ref.numpy()), float(same.float().mean()),
+                                        int((~safe).sum()), safe.numel()))
+        assert e < tol, k
+        if precision == 'fp32':
+            assert bool(same[safe].all()), 'argmax differs outside the round-off margin (level %s)' % k
+    ltol = FP32_TOL if precision == 'fp32' else 2e-2
+    assert abs(loss.item() - r['loss']) < ltol * abs(r['loss']), (loss.item(), r['loss'])
+    gscale = max(float(v.abs().max()) for v in r['grad'].values())
+    # gradients: rel-L2 and max-entry error of the whole tensors.
+    # Layer 3 (no ReLU behind it): fp32 1e-4, bf16 2e-2 -- measured 1e-7..3e-6 and 1e-4..7e-3.
+    # Layers 1-2: the gradient passes through ReLU masks.  Of the oracle's ~200 M ReLU inputs at this size, ~1e-5
+    # (fp32) / ~1e-2 (bf16) lie within the other implementation's round-off of zero and get the opposite mask, which
+    # moves sums over ~1 M positions by ~1e-3 (fp32, measured 0.3-1.6e-3 rel-L2) / ~7e-2 (bf16, measured 5-8e-2):
+    # the error JUMPS between layer 3 and layer 2 and does not grow from layer 2 to layer 1 -- the signature of mask
+    # flips, not of accumulated arithmetic error (the fixtures, chosen for their ReLU margin, match at 2e-6 in fp32).
+    # Gates: fp32 5e-3 rel-L2 / 2e-2 per entry; bf16 0.15 / 0.3.
+    g_l2, g_max = (5e-3, 2e-2) if precision == 'fp32' else (0.15, 0.3)
+    g3_l2, g3_max = (1e-4, 1e-4) if precision == 'fp32' else (2e-2, 2e-2)
+    rows = []
+    for key, p in m.named_parameters():
+        ref = 2.0 * r['grad'][key]
+        got = p.grad.detach().cpu()
+        if key.endswith('conv1.bias') or key.endswith('conv2.bias') or key.endswith('conv3.bias'):
+            assert float(got.abs().max()) < (1e-4 if precision == 'fp32' else 2e-2) * 2 * gscale, key
+            continue
+        rows.append((key, rel_err(got.numpy(), ref.numpy()), max_rel_err(got.numpy(), ref.numpy())))
+    for key, el2, emax in rows:
+        print('%s full size grad %-18s rel-L2 %.2e, max / scale %.2e' % (precision, key, el2, emax))
+    for key, el2, emax in rows:
+        layer3 = key.split('.')[0] in ('fast_conv3', 'slow_conv3', 'bn_f3', 'bn_s3')
+        assert el2 < (g3_l2 if layer3 else g_l2) and emax < (g3_max if layer3 else g_max), (key, el2, emax)
+    for key, b in m.named_buffers():
+        ref = r['stat'][key]
+        if key.endswith('num_batches_tracked'):
+            assert int(b) == int(ref)
+        else:
+            assert max_rel_err(b.cpu().numpy(), ref.numpy()) < (FP32_TOL if precision == 'fp32' else 2e-2), key
+    opt.step()
+    for key, p in m.named_parameters():
+        ref = r['param'][key]
+        d = float((p.detach().cpu() - ref).abs().max())
+        assert d <= (1e-5 if precision == 'fp32' else 1e-3) * float(ref.abs().max()) + 1e-9, (key, d)
 
 
-def test_packed_clip_matches_frame_lists_and_backward():
-    """enhance_packed (channels-last hand-over) == temporally_enhance_features on the same data,
-    forward and parameter gradients, fp32."""
+def _oracle_clip(sp, fp, fast_cpu, train=True):
+    """CPU oracle on one clip (dict level -> [fp,256,H,W] fp32): fused maps, loss, parameter gradients."""
+    from oracle.closed_form import slice_slow
+    o = OracleSlowFastLayers(256, torch.device('cpu'), sp, fp)
+    o.load_state_dict(closed_form_state_dict(o))
+    o.train(train)
+    out = o.temporally_enhance_features([slice_slow(fast_cpu, sp)], [fast_cpu])
+    loss = proxy_loss(out)
+    loss.backward()
+    return ({k: v.detach() for k, v in out.items()}, float(loss),
+            {k: p.grad.detach().clone() for k, p in o.named_parameters()})
+
+
+def _assert_grads_match(m, ref_g, tol, what, tol_max=None):
+    """rel-L2 of every parameter gradient below tol (and, when given, every entry within tol_max of the scale)."""
+    gscale = max(float(v.abs().max()) for v in ref_g.values())
+    for key, p in m.named_parameters():
+        if key.endswith('conv1.bias') or key.endswith('conv2.bias') or key.endswith('conv3.bias'):
+            assert float(p.grad.abs().max()) < max(tol, 1e-4) * gscale, (what, key)   # true gradient 0
+            continue
+        e = rel_err(p.grad.cpu().numpy(), ref_g[key].numpy())
+        assert e < tol, (what, key, e)
+        if tol_max is not None:
+            assert max_rel_err(p.grad.cpu().numpy(), ref_g[key].numpy()) < tol_max, (what, key)
+
+
+def test_packed_clip_matches_the_oracle_and_frame_lists():
+    """enhance_packed (channels-last hand-over) against the CPU oracle on the same clip -- fused maps,
+    loss and every parameter gradient, fp32 at 1e-3 -- and, as an extra, bit-identical to temporally_enhance_features
+    on the same data."""
     from sfvos_amd import PackedClip
     sp, fp = 3, 7
     m, dev = build(sp, fp, 'fp32')
     m.train()
     slow, fast = clip_inputs(sp, fp, SMALL_LEVELS, 0, dev)
+    ref_out, ref_loss, ref_g = _oracle_clip(sp, fp, OrderedDict((k, v.cpu()) for k, v in fast[0].items()))
     out = m.temporally_enhance_features(slow, fast)
     proxy_loss(out).backward()
-    ref_g = {k: p.grad.clone() for k, p in m.named_parameters()}
-    m.zero_grad()
+    frames_g = {k: p.grad.clone() for k, p in m.named_parameters()}
     m2, _ = build(sp, fp, 'fp32')
     m2.train()
     levels = [fast[0][k].permute(0, 2, 3, 1).unsqueeze(0).contiguous() for k in SMALL_LEVELS]   # [1,T,H,W,C]
     clip = PackedClip.from_levels(levels, keys=list(SMALL_LEVELS.keys()))
     out2 = m2.enhance_packed(clip)
+    loss2 = proxy_loss(out2)
+    loss2.backward()
+    for k in out2:
+        assert max_rel_err(out2[k].detach().cpu().numpy(), ref_out[k].numpy()) < FP32_TOL, k
+        assert torch.equal(out2[k].argmax(1).cpu(), ref_out[k].argmax(1)), k
+        assert torch.equal(out[k], out2[k])
+    assert abs(loss2.item() - ref_loss) < FP32_TOL * abs(ref_loss)
+    _assert_grads_match(m2, ref_g, FP32_TOL, 'packed', FP32_TOL)
+    for k, p in m2.named_parameters():
+        assert torch.equal(p.grad, frames_g[k]), k
+
+
+@pytest.mark.parametrize('precision,pad', [('fp32', (2, 0)), ('fp32', (0, 3)), ('bf16', (1, 2)), ('bf16', (3, 0))])
+def test_packed_clip_zero_frames_by_pointer_match_the_oracle(precision, pad):
+    """The reference pads windows that stick out of the sequence with zero FEATURE frames (model.py:215-225).  A
+    PackedClip stores only the real frames and names the padding (pad=(before, after)): the padding frames have no
+    storage at all -- in the level-major buffer the positions "before" a level's first frame belong to the previous
+    level -- so any read of them would show up as a wrong result.  Checked against the CPU oracle fed with explicit zero
+    frames: fused maps, loss, parameter gradients (train mode), both dtypes / layouts, and the gradient w.r.t. the
+    stored frames comes back in the clip's own shape."""
+    from sfvos_amd import PackedClip
+    sp, fp = 3, 7
+    m, dev = build(sp, fp, precision)
+    m.train()
+    n_real = fp - pad[0] - pad[1]
+
+    def make(clip_id):
+        real = closed_form_features(n_real, SMALL_LEVELS, clip=clip_id)
+        if precision == 'bf16':
+            real = OrderedDict((k, v.bfloat16().float()) for k, v in real.items())
+        window = OrderedDict((k, torch.cat([torch.zeros(pad[0], *v.shape[1:]), v, torch.zeros(pad[1], *v.shape[1:])]))
+                             for k, v in real.items())
+        return real, window
+    # like oracle/make_golden.py: among 24 closed-form clips take the one whose ReLU inputs stay farthest from zero
+    # in the oracle, so that no mask can flip between two correct fp32 implementations
+    from oracle.closed_form import slice_slow
+    o = OracleSlowFastLayers(256, torch.device('cpu'), sp, fp)
+    o.load_state_dict(closed_form_state_dict(o))
+    o.train()
+    best = (-1.0, 0)
+    with torch.no_grad():
+        for cid in range(24):
+            _, w_ = make(cid)
+            o.relu_margins = []
+            o.temporally_enhance_features([slice_slow(w_, sp)], [w_])
+            best = max(best, (min(o.relu_margins), cid))
+    real, window = make(best[1])
+    ref_out, ref_loss, ref_g = _oracle_clip(sp, fp, window)
+    tdt = torch.bfloat16 if precision == 'bf16' else torch.float32
+    levels = [real[k].to(dev).permute(0, 2, 3, 1).unsqueeze(0).to(tdt).contiguous() for k in SMALL_LEVELS]
+    clip = PackedClip.from_levels(levels, keys=list(SMALL_LEVELS.keys()),
+                                  layout='grouped' if precision == 'bf16' else 'ndhwc', pad=pad)
+    assert clip.frames == n_real and clip.window == fp
+    clip.data.requires_grad_(True)
+    out = m.enhance_packed(clip)
+    loss = proxy_loss(out)
+    loss.backward()
+    tol = FP32_TOL if precision == 'fp32' else 5e-2
+    for k in out:
+        assert max_rel_err(out[k].detach().cpu().numpy(), ref_out[k].numpy()) < tol, k
+    assert abs(loss.item() - ref_loss) < (FP32_TOL if precision == 'fp32' else 2e-2) * abs(ref_loss)
+    # gradients against the oracle: fp32 1e-3 rel-L2 (ReLU margin of the chosen clip %.1e); bf16 0.15 (bf16 activations
+    # flip ~1 %% of the ReLU masks: see test_full_size_headline_config_matches_the_oracle)
+    print('zero-frame clip %d: min |ReLU input| in the oracle %.2e' % (best[1], best[0]))
+    _assert_grads_match(m, ref_g, FP32_TOL if precision == 'fp32' else 0.15, 'padded clip')
+    # ... and BIT-IDENTICAL to the same module fed the window with materialised zero frames: a zero frame produced by
+    # an empty buffer descriptor and a stored zero frame put the same bytes into LDS
+    m2, _ = build(sp, fp, precision)
+    m2.train()
+    full = [window[k].to(dev).permute(0, 2, 3, 1).unsqueeze(0).to(tdt).contiguous() for k in SMALL_LEVELS]
+    clip2 = PackedClip.from_levels(full, keys=list(SMALL_LEVELS.keys()), layout='grouped' if precision == 'bf16' else 'ndhwc')
+    clip2.data.requires_grad_(True)
+    out2 = m2.enhance_packed(clip2)
     proxy_loss(out2).backward()
     for k in out:
-        assert torch.equal(out[k], out2[k])
-    for k, p in m2.named_parameters():
-        assert torch.equal(p.grad, ref_g[k]), k
+        assert torch.equal(out[k], out2[k]), k
+    for (k, p), (_, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p.grad, p2.grad), k
+    g_full = clip2.data.grad if precision == 'fp32' else clip2.data.grad.permute(1, 0, 2).reshape(clip2.data.shape[1], -1)
+    g_part = clip.data.grad if precision == 'fp32' else clip.data.grad.permute(1, 0, 2).reshape(clip.data.shape[1], -1)
+    off_f = off_p = 0
+    for (H, W) in SMALL_LEVELS.values():   # the stored frames' gradient = those frames of the full window's gradient
+        a = g_full[off_f: off_f + fp * H * W].view(fp, H * W, -1)[pad[0]: pad[0] + n_real]
+        b = g_part[off_p: off_p + n_real * H * W].view(n_real, H * W, -1)
+        assert torch.equal(a, b)
+        off_f += fp * H * W
+        off_p += n_real * H * W
+    assert clip.data.grad is not None and clip.data.grad.shape == clip.data.shape
+    assert bool(torch.isfinite(clip.data.grad.float()).all()) and float(clip.data.grad.float().abs().max()) > 0
+    with pytest.raises(RuntimeError):
+        m.enhance_packed(PackedClip.from_levels(levels, keys=list(SMALL_LEVELS.keys()),
+                                                layout='grouped' if precision == 'bf16' else 'ndhwc', pad=(pad[0] + 1, pad[1])))
 
 
 def test_grouped_packed_clip_matches_ndhwc_and_returns_grouped_input_gradient():

@@ -105,10 +105,34 @@ def test_cabi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.sfvos_version.restype = ctypes.c_int
-    assert lib.sfvos_version() >= 100
-    # struct mirrors: sizes must match the C structs (13 ints + sfvos_pyramid{int, int[8], int[8]})
-    assert ctypes.sizeof(_lib.Pyramid) == 68 and ctypes.sizeof(_lib.ConvDesc) == 144
-    assert ctypes.sizeof(_lib.Levels) == 72
+    assert lib.sfvos_version() >= 200
+    # struct mirrors: the binder's sizes must be the ones the library was compiled with (sfvos_abi_sizes); _lib.load()
+    # enforces the same at import time
+    sizes = (ctypes.c_int * 4)()
+    assert lib.sfvos_abi_sizes(sizes, 4) == 4
+    assert list(sizes) == [ctypes.sizeof(_lib.ConvDesc), ctypes.sizeof(_lib.Pyramid), ctypes.sizeof(_lib.Levels),
+                           ctypes.sizeof(_lib.MseTable)]
+    assert ctypes.sizeof(_lib.Pyramid) == 68 and ctypes.sizeof(_lib.ConvDesc) == 152 and ctypes.sizeof(_lib.Levels) == 72
+    assert _lib.ConvDesc().struct_size == 152
+    _lib.load()
+
+
+def test_integration_doc_shows_the_real_conv_desc():
+    """INTEGRATION.md's ctypes mirror of sfvos_conv_desc must list exactly the fields of the binding in use."""
+    from sfvos_amd import _lib
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    block = doc[doc.index('class ConvDesc(C.Structure):'):doc.index('lib.sfvos_conv3d.restype')]
+    names = re.findall(r"\('([a-z_]+)',", block)
+    assert names == [f[0] for f in _lib.ConvDesc._fields_], names
+
+
+def test_bench_timed_region_never_touches_oracle():
+    """bench.py may use oracle/ only inside cpu_baseline() (the reported CPU leg)."""
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    hits = [m.start() for m in re.finditer(r'^\s*(from|import)\s+oracle', src, re.M)]
+    lo = src.index('def cpu_baseline(')
+    hi = src.index('def pmc_traffic(')
+    assert hits and all(lo < h < hi for h in hits), 'oracle imported outside cpu_baseline()'
 
 
 def test_shard_clips():
@@ -116,3 +140,22 @@ def test_shard_clips():
     assert shard_clips(10, 0, 4) == [0, 4, 8] and shard_clips(10, 3, 4) == [3, 7]
     got = sorted(i for r in range(8) for i in shard_clips(37, r, 8))
     assert got == list(range(37))
+
+
+def test_stale_conv_desc_is_refused_before_any_launch():
+    """A binder that passes a shorter / older sfvos_conv_desc (INTEGRATION.md once showed one) gets an error,
+    not a kernel launched on strides read from past the end of its struct.  Host logic only: no GPU needed."""
+    from sfvos_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('libsfvos.so not built (run `python __graft_entry__.py`)')
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    d.dtype, d.batch, d.t_in, d.t_alloc, d.t_offset = _lib.BF16, 1, 7, 7, 0
+    d.c_in, d.c_out, d.kt, d.taps, d.pad_t, d.ld_x, d.ld_y = 256, 32, 3, 9, 0, 256, 32
+    d.pyr = _lib.make_pyramid([(12, 21)])
+    assert lib.sfvos_conv3d_stat_rows(ctypes.byref(d), None) > 0
+    assert lib.sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d)) > 0
+    d.struct_size -= 16
+    assert lib.sfvos_conv3d_stat_rows(ctypes.byref(d), None) < 0
+    assert b'struct_size' in lib.sfvos_last_error()
+    assert lib.sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d)) == 0

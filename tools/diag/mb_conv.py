@@ -9,6 +9,42 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sfvos_amd import _lib, davis_pyramid  # noqa: E402
 
+# SFVOS_LEGACY=1 + SFVOS_LIB=<round-1 build>: A/B against the round-1 ABI (no struct_size, a `zeros` argument)
+LEGACY = os.environ.get('SFVOS_LEGACY') == '1'
+if LEGACY:
+    class LegacyDesc(ctypes.Structure):
+        _fields_ = [f for f in _lib.ConvDesc._fields_ if f[0] != 'struct_size']
+    _raw = ctypes.CDLL(_lib.LIB_PATH)
+    _Z = None
+
+    class _Shim(object):
+        ConvDesc, BF16, FP8, MAX_LEVELS = LegacyDesc, _lib.BF16, _lib.FP8, _lib.MAX_LEVELS
+        make_pyramid = staticmethod(_lib.make_pyramid)
+
+        @staticmethod
+        def load():
+            return _raw
+
+        @staticmethod
+        def call(name, *args):
+            global _Z
+            if _Z is None:
+                _Z = torch.zeros(1024, dtype=torch.uint8, device='cuda')
+            if name in ('sfvos_conv3d', 'sfvos_conv3d_wgrad'):
+                args = args[:-1] + (ctypes.c_void_p(_Z.data_ptr()), args[-1])
+            conv = []
+            for a in args:
+                if isinstance(a, float):
+                    a = ctypes.c_float(a)
+                conv.append(a)
+            fn = getattr(_raw, name)
+            fn.restype = ctypes.c_int
+            rc = fn(*conv)
+            if rc != 0:
+                raise RuntimeError('%s failed %d' % (name, rc))
+    _raw.sfvos_conv3d_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    _lib = _Shim
+
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 S = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 SHAPES = [s for _, s in davis_pyramid()]
@@ -41,9 +77,8 @@ def conv(name, T, cin, cout, kt, taps, pad_t=0, reps=5, shapes=SHAPES, acc=0):
     y = torch.empty(t_out * pix, cout, device='cuda', dtype=torch.bfloat16)
     rows = _lib.load().sfvos_conv3d_stat_rows(ctypes.byref(d), None)
     part = torch.empty(rows, 2, cout, device='cuda')
-    z = torch.zeros(1024, dtype=torch.uint8, device='cuda')
     pp = None if pad_t > 0 else P(part)
-    ms = timeit(lambda: _lib.call('sfvos_conv3d', ctypes.byref(d), P(x), P(wp), None, P(y), pp, P(z), S()), reps)
+    ms = timeit(lambda: _lib.call('sfvos_conv3d', ctypes.byref(d), P(x), P(wp), None, P(y), pp, S()), reps)
     fl = 2.0 * cin * cout * kt * taps * t_out * pix
     print('conv  %-22s dbg=%s %8.3f ms %7.1f TF/s' % (name, os.environ.get('SFVOS_CONV_DEBUG', '0'), ms, fl / ms / 1e9),
           flush=True)
@@ -65,8 +100,7 @@ def conv_fp8(name, T, cin, cout, kt, reps=5, shapes=SHAPES):
     y = torch.empty(t_out * pix, cout, device='cuda', dtype=torch.bfloat16)
     rows = _lib.load().sfvos_conv3d_stat_rows(ctypes.byref(d), None)
     part = torch.empty(rows, 2, cout, device='cuda')
-    z = torch.zeros(1024, dtype=torch.uint8, device='cuda')
-    ms = timeit(lambda: _lib.call('sfvos_conv3d', ctypes.byref(d), P(x), P(wp), P(bd), P(y), P(part), P(z), S()), reps)
+    ms = timeit(lambda: _lib.call('sfvos_conv3d', ctypes.byref(d), P(x), P(wp), P(bd), P(y), P(part), S()), reps)
     fl = 2.0 * cin * cout * kt * 9 * t_out * pix
     print('conv  %-22s fp8     %8.3f ms %7.1f TF/s' % (name, ms, fl / ms / 1e9), flush=True)
 
@@ -78,8 +112,7 @@ def wgrad(name, T, cin, cout, kt, taps, reps=5, shapes=SHAPES):
     dy = torch.randn(t_out * pix, cout, device='cuda').bfloat16()
     gw = torch.empty(cout * cin * kt * taps, device='cuda')
     ws = torch.empty(_lib.load().sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d)), dtype=torch.uint8, device='cuda')
-    z = torch.zeros(1024, dtype=torch.uint8, device='cuda')
-    ms = timeit(lambda: _lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(x), P(dy), P(gw), 0, P(ws), P(z), S()), reps)
+    ms = timeit(lambda: _lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(x), P(dy), P(gw), 0, P(ws), S()), reps)
     fl = 2.0 * cin * cout * kt * taps * t_out * pix
     print('wgrad %-22s       %8.3f ms %7.1f TF/s  (slab %.0f MB)' % (name, ms, fl / ms / 1e9, ws.numel() / 1e6), flush=True)
 
