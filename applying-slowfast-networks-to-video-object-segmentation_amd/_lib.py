@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
     rejects a descriptor whose size differs from its own struct (stale binding)."""
     _fields_ = [('struct_size', i32), ('dtype', i32), ('batch', i32), ('t_in', i32), ('t_alloc', i32), ('t_offset', i32), ('c_in', i32),
                 ('c_out', i32), ('kt', i32), ('taps', i32), ('pad_t', i32), ('ld_x', i32), ('ld_y', i32),
-                ('accumulate', i32), ('pyr', Pyramid), ('x_group_stride', i64), ('x_frame_stride', i64), ('y_frame_stride', i64)]
+                ('accumulate', i32), ('relu', i32), ('pyr', Pyramid), ('x_group_stride', i64), ('x_frame_stride', i64), ('y_frame_stride', i64)]
 
 
     def __init__(self, *args, **kw):
@@ -101,6 +101,10 @@ SIGNATURES = {
     'sfvos_mse_loss': (i32, [PM, vp, vp, vp]),
     'sfvos_mse_loss_grad': (i32, [PM, vp, vp]),
     'sfvos_mask_union': (i32, [vp, i32, i64, f32, vp, vp]),
+    'sfvos_pack_deconv2x2': (i32, [vp, vp, i32, i32, i32, vp]),
+    'sfvos_deconv2x2_relu': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    'sfvos_mask_logits': (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+    'sfvos_paste_masks': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
 }
 
 _lib = None

@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libsfvos.so')
-SOURCES = ['runtime.hip', 'elementwise.hip', 'batchnorm.hip', 'conv3d.hip', 'wgrad.hip', 'lateral.hip']
+SOURCES = ['runtime.hip', 'elementwise.hip', 'batchnorm.hip', 'conv3d.hip', 'wgrad.hip', 'lateral.hip', 'maskhead.hip']
 HEADERS = ['common.h', 'elt_util.h']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
@@ -33,7 +33,7 @@ def build(force=False, verbose=False):
             return o, True
         return o, False
 
-    with ThreadPoolExecutor(max_workers=6) as ex:
+    with ThreadPoolExecutor(max_workers=7) as ex:
         results = list(ex.map(compile_one, SOURCES))
     objs = [o for o, _ in results]
     if force or any(ch for _, ch in results) or not os.path.exists(LIB):

@@ -65,7 +65,7 @@ struct ConvArgs {
   const float* bias;
   char* y;
   float* stat_part;
-  int batch, t_in, t_alloc, t_offset, t_out, c_in, c_out, kt, pad_t, ld_x, ld_y, accumulate;
+  int batch, t_in, t_alloc, t_offset, t_out, c_in, c_out, kt, pad_t, ld_x, ld_y, accumulate, relu;
   // x addressing: element (position, chunk cc of 64 bytes) at x + cc*x_chunk_bytes + position*x_pitch_bytes:
   // pyramid NDHWC = (64, ld_x*ES); channel-group-major input = (group stride in bytes, 64)
   long long x_chunk_bytes;
@@ -365,7 +365,8 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int px = (e & 3) + 8 * (e >> 2) + 4 * hh;
-          const float v = acc[j][i][q][e] + bias;
+          float v = acc[j][i][q][e] + bias;
+          if (a.relu) v = fmaxf(v, 0.f);
           scr[px * 33 + r] = v;
           if (w0 + px < W) { s1[q] += v; s2[q] += v * v; }
         }
@@ -762,7 +763,8 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int px = 4 * g16 + e;
-          const float v0 = acc16[i][0][e] + bias0, v1 = acc16[i][1][e] + bias1;
+          float v0 = acc16[i][0][e] + bias0, v1 = acc16[i][1][e] + bias1;
+          if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
           scr[px * 33 + p16] = v0;
           scr[px * 33 + 16 + p16] = v1;
           if (w0 + kh * 16 + px < W) { s1 += v0; s2 += v0 * v0; s1b += v1; s2b += v1 * v1; }
@@ -841,7 +843,8 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
   #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int px = (e & 3) + 8 * (e >> 2) + 4 * hh;
-          const float v = F8 ? fin[ii][e] * desc + bias : fin[ii][e] + bias;
+          float v = F8 ? fin[ii][e] * desc + bias : fin[ii][e] + bias;
+          if (a.relu) v = fmaxf(v, 0.f);
           scr[px * 33 + r] = v;
           if (w0 + px < W) { s1 += v; s2 += v * v; }
         }
@@ -1183,6 +1186,7 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
   if (rc != SFVOS_OK) return rc;
   SFVOS_REQUIRE(x && w_packed && y, "conv: null pointer");
   SFVOS_REQUIRE(!(stat_part && d->accumulate), "conv: statistics are those of the conv result; not available with accumulate");
+  SFVOS_REQUIRE(!(d->relu && (stat_part || d->accumulate)), "conv: the ReLU epilogue excludes statistics and accumulate");
   SFVOS_REQUIRE(d->ld_y % (d->dtype == SFVOS_F32 ? 4 : 8) == 0, "conv: ld_y %d must be a multiple of a 16-byte chunk", d->ld_y);
   SFVOS_REQUIRE(d->dtype != SFVOS_FP8 || bias != nullptr, "conv: e4m3 operands need the [2][c_out] (bias, descale) rows");
   SFVOS_REQUIRE(!(d->taps == 1 && p.family == 2), "conv: 1x1 conv with c_out > 64 has no kernel instance");
@@ -1191,7 +1195,7 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
   lateral_ok = !getenv("SFVOS_NO_LATERAL_KERNEL");
 #endif
   if (!bias && !stat_part && d->taps == 1 && d->x_group_stride == 0 && d->x_frame_stride == 0 &&
-      d->y_frame_stride == 0 && lateral_ok) {
+      d->y_frame_stride == 0 && !d->relu && lateral_ok) {
     rc = lateral_dgrad_try(d, x, w_packed, y, (hipStream_t)stream);  // lateral data gradient: its own HBM-bound kernel
     if (rc >= 0) return rc;
   }
@@ -1199,7 +1203,7 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
   a.x = (const char*)x; a.wp = (const char*)w_packed; a.bias = bias; a.y = (char*)y; a.stat_part = stat_part;
   a.batch = d->batch; a.t_in = d->t_in; a.t_alloc = d->t_alloc; a.t_offset = d->t_offset; a.t_out = p.t_out;
   a.c_in = d->c_in; a.c_out = d->c_out; a.kt = d->kt;
-  a.pad_t = d->pad_t; a.ld_x = d->ld_x; a.ld_y = d->ld_y; a.accumulate = d->accumulate;
+  a.pad_t = d->pad_t; a.ld_x = d->ld_x; a.ld_y = d->ld_y; a.accumulate = d->accumulate; a.relu = d->relu;
   const int es = d->dtype == SFVOS_BF16 ? 2 : d->dtype == SFVOS_FP8 ? 1 : 4;  // bytes per element of x
   a.x_pitch_bytes = d->x_group_stride ? 64 : d->ld_x * es;
   a.x_chunk_bytes = d->x_group_stride ? d->x_group_stride * es : 64;

@@ -164,6 +164,8 @@ typedef struct sfvos_conv_desc {
   int pad_t;       /* zero frames each side in time: 0 (forward), kt-1 (data gradient) */
   int ld_x, ld_y;  /* per-position pitch of x / y in elements */
   int accumulate;  /* y += conv(x) instead of y = conv(x)  (gradient fan-in) */
+  int relu;        /* y = max(conv(x) + bias, 0): the conv3x3 + ReLU blocks of the mask head (no statistics, no
+                    * accumulate with it) */
   sfvos_pyramid pyr; /* spatial extents of the levels (stride 1: output spatial == input spatial) */
   int64_t x_group_stride; /* 0: x is pyramid NDHWC with pitch ld_x.  > 0 (bf16 only): x is stored as 64-byte
                            * channel groups, element (position, c) at (c/32)*x_group_stride + position*32 + c%32
@@ -286,6 +288,28 @@ int sfvos_mse_loss(const sfvos_mse_table* t, float* part, float* loss, sfvos_str
 /* grad_l[i] = upstream * 2 (out_l[i] - target_l[i]) / numel_l; upstream: device scalar (autograd's grad_output) or
  * NULL for 1. */
 int sfvos_mse_loss_grad(const sfvos_mse_table* t, const float* upstream, sfvos_stream_t stream);
+
+/* ---- mask branch behind RoIAlign (model.py:17-25 MaskRCNNPredictor(256, 256, 2), model.py:346-347) -----
+ * torchvision's MaskRCNNHeads / MaskRCNNPredictor / maskrcnn_inference / paste_masks_in_image on RoI features
+ * [N,256,14,14] (RoIAlign itself is torchvision, out of scope).  The four conv3x3 + ReLU blocks are sfvos_conv3d calls
+ * (kt = 1, taps = 9, relu = 1, batch = N RoIs, one 14x14 "level"); the rest: */
+
+/* ConvTranspose2d(Cin, Cout, 2, 2, 0) weight [Cin][Cout][2][2] fp32 -> packed image (4*Cin*Cout elements of dtype). */
+int sfvos_pack_deconv2x2(const float* w, void* packed, int dtype, int c_in, int c_out, sfvos_stream_t stream);
+/* y[n][2i+a][2j+b][co] = act(bias[co] + sum_ci x[n][i][j][ci] * w[ci][co][a][b]); x: NHWC [n][h][w][c_in], y: NHWC
+ * [n][2h][2w][c_out], both `dtype`; act = ReLU when relu != 0 (conv5_mask + relu of MaskRCNNPredictor). */
+int sfvos_deconv2x2_relu(const void* x, const void* w_packed, const float* bias, void* y, int dtype, int n, int h, int w,
+                         int c_in, int c_out, int relu, sfvos_stream_t stream);
+/* mask_fcn_logits (conv1x1 c -> num_classes, weight [num_classes][c] fp32) on x: NHWC [n][positions][c]:
+ * logits (may be NULL): [n][num_classes][positions] fp32; prob (may be NULL): [n][1][positions] = sigmoid of the logit
+ * of class labels[n] (maskrcnn_inference). */
+int sfvos_mask_logits(const void* x, int dtype, const float* w, const float* bias, const int64_t* labels, int n,
+                      int positions, int c, int num_classes, float* logits, float* prob, sfvos_stream_t stream);
+/* paste_masks_in_image: masks [n][1][mask_size][mask_size] fp32, boxes [n][4] fp32 (x1,y1,x2,y2) -> out
+ * [n][1][img_h][img_w] fp32: masks zero-padded by `padding`, boxes expanded by (mask_size + 2 padding) / mask_size
+ * and truncated to integers, bilinear resize (align_corners = false) to the box, zero outside it. */
+int sfvos_paste_masks(const float* masks, const float* boxes, int n, int mask_size, int padding, int img_h, int img_w,
+                      float* out, sfvos_stream_t stream);
 
 /* ---- evaluation-side reducer (reference code/helpers/davis_evaluate.py:40-42) ------------ */
 

@@ -159,3 +159,19 @@ def test_stale_conv_desc_is_refused_before_any_launch():
     assert lib.sfvos_conv3d_stat_rows(ctypes.byref(d), None) < 0
     assert b'struct_size' in lib.sfvos_last_error()
     assert lib.sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d)) == 0
+
+
+def test_mask_branch_surface_matches_torchvision_names():
+    """MaskBranch mirrors roi_heads.mask_head / roi_heads.mask_predictor of torchvision's Mask R-CNN as the reference
+    configures it (model.py:17-25): same state-dict keys and shapes as the torch-core restatement."""
+    from oracle.mask_head_ref import OracleMaskBranch
+    from sfvos_amd import MaskBranch
+    m, o = MaskBranch(256, 2), OracleMaskBranch(256, 2)
+    sm, so = m.state_dict(), o.state_dict()
+    assert list(sm.keys()) == list(so.keys())
+    assert 'mask_head.mask_fcn4.weight' in sm and 'mask_predictor.conv5_mask.weight' in sm
+    assert tuple(sm['mask_predictor.conv5_mask.weight'].shape) == (256, 256, 2, 2)
+    assert tuple(sm['mask_predictor.mask_fcn_logits.weight'].shape) == (2, 256, 1, 1)
+    for k in sm:
+        assert sm[k].shape == so[k].shape
+    m.load_state_dict(so, strict=True)
