@@ -21,7 +21,7 @@ struct FinalizeTab {
 
 constexpr int BNB_THREADS = 256;
 constexpr int BNB_POS = 512;      // positions per block iteration
-constexpr int BNB_MAX_ROWS = 1024;  // per level
+constexpr int BNB_MAX_ROWS = 512;  // per level
 
 static int make_level_tab(const sfvos_levels* lv, LevelTab* t, const char* what) {
   SFVOS_REQUIRE(lv != nullptr && lv->n_levels >= 1 && lv->n_levels <= SFVOS_MAX_LEVELS, "%s: bad level count", what);
@@ -91,8 +91,9 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 }
 
 __global__ void bn_running_update_kernel(float* rm, float* rv, const float* means, const float* vars, int n, int cs,
-                                         int C, float momentum) {
+                                         int C, float momentum, long long* num_batches_tracked) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += n;  // one forward per level (model.py:156-159)
   if (c < C) {
     float m = rm[c], v = rv[c];
     for (int i = 0; i < n; ++i) {
@@ -134,7 +135,8 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_bwd_kernel(
     const char* __restrict__ dy, int ld_dy, const char* __restrict__ x, int ld_x, char* dx, int ld_dx, LevelTab lt,
     int C, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ rstd, int cs, int relu, const float* __restrict__ cA, const float* __restrict__ cB,
-    const float* __restrict__ cK, float* part) {
+    const float* __restrict__ cK, float* part, const float* __restrict__ sum_dz, const float* __restrict__ sum_dzx,
+    float* dgamma, float* dbeta, int accumulate) {
   constexpr int CE = Elt<DT>::CE, ES = 16 / CE;
   int lvl = 0;
 #pragma unroll
@@ -199,6 +201,18 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_bwd_kernel(
       }
     }
   }
+  if (APPLY && blockIdx.x == 0 && (dgamma || dbeta)) {
+    // dgamma / dbeta: the per-level sums of pass 1 (bn_bwd_finalize), added in level order
+    for (int cc = threadIdx.x; cc < C; cc += BNB_THREADS) {
+      double tg = 0.0, tb = 0.0;
+      for (int l = 0; l < lt.n; ++l) {
+        tg += (double)sum_dzx[(long long)l * cs + cc];
+        tb += (double)sum_dz[(long long)l * cs + cc];
+      }
+      if (dgamma) dgamma[cc] = (accumulate ? dgamma[cc] : 0.f) + (float)tg;
+      if (dbeta) dbeta[cc] = (accumulate ? dbeta[cc] : 0.f) + (float)tb;
+    }
+  }
   if (part == nullptr) return;
   __shared__ float red[2][BNB_THREADS][8];
 #pragma unroll
@@ -217,41 +231,36 @@ __global__ __launch_bounds__(BNB_THREADS) void bn_bwd_kernel(
   }
 }
 
-// dgamma/dbeta (summed over levels in level order) and the per-level pass-2 coefficients.
-// grid = C/32; block = 32 channels x RL row lanes.
+// Per level: the sums of pass 1 reduced in fixed order, and the pass-2 coefficients.  grid = (C/32, n_levels);
+// block = 32 channels x RL row lanes.  (dgamma / dbeta = the per-level sums added over the levels: done by block 0 of
+// the pass-2 kernel, so that this tiny kernel runs all levels in parallel instead of one after the other.)
 __global__ __launch_bounds__(32 * RL) void bn_bwd_finalize_kernel(const float* part, LevelTab lt, const float* gamma,
                                                                   const float* mean, const float* rstd, int cs, int C,
-                                                                  int train, int accumulate, float* dgamma,
-                                                                  float* dbeta, float* cA, float* cB, float* cK) {
+                                                                  int train, float* cA, float* cB, float* cK,
+                                                                  float* sum_dz, float* sum_dzx) {
   __shared__ double scratch[32 * RL];
+  const int l = blockIdx.y;
   const int c_local = threadIdx.x & 31, sub = threadIdx.x >> 5, c = blockIdx.x * 32 + c_local;
-  double tg = 0.0, tb = 0.0;
-  for (int l = 0; l < lt.n; ++l) {
-    const float* p = part + (long long)lt.blk_begin[l] * 2 * C;
-    const int rows = lt.blk_begin[l + 1] - lt.blk_begin[l];
-    const double count = (double)(lt.mb[l + 1] - lt.mb[l]);
-    const double sdz = column_sum(p, rows, 2 * C, c, sub, scratch, c_local);
-    const double sdzx = column_sum(p, rows, 2 * C, C + c, sub, scratch, c_local);
-    if (sub == 0) {
-      tg += sdzx;
-      tb += sdz;
-      const long long o = (long long)l * cs + c;
-      const double g = (double)gamma[c] * (double)rstd[o];
-      if (train) {
-        const double m1 = sdz / count, m2 = sdzx / count;
-        cA[o] = (float)g;
-        cB[o] = (float)(-g * m2 * (double)rstd[o]);
-        cK[o] = (float)(g * m2 * (double)rstd[o] * (double)mean[o] - g * m1);
-      } else {
-        cA[o] = (float)g;
-        cB[o] = 0.f;
-        cK[o] = 0.f;
-      }
-    }
-  }
+  const float* p = part + (long long)lt.blk_begin[l] * 2 * C;
+  const int rows = lt.blk_begin[l + 1] - lt.blk_begin[l];
+  const double count = (double)(lt.mb[l + 1] - lt.mb[l]);
+  const double sdz = column_sum(p, rows, 2 * C, c, sub, scratch, c_local);
+  const double sdzx = column_sum(p, rows, 2 * C, C + c, sub, scratch, c_local);
   if (sub == 0) {
-    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)tg;
-    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)tb;
+    const long long o = (long long)l * cs + c;
+    sum_dz[o] = (float)sdz;
+    sum_dzx[o] = (float)sdzx;
+    const double g = (double)gamma[c] * (double)rstd[o];
+    if (train) {
+      const double m1 = sdz / count, m2 = sdzx / count;
+      cA[o] = (float)g;
+      cB[o] = (float)(-g * m2 * (double)rstd[o]);
+      cK[o] = (float)(g * m2 * (double)rstd[o] * (double)mean[o] - g * m1);
+    } else {
+      cA[o] = (float)g;
+      cB[o] = 0.f;
+      cK[o] = 0.f;
+    }
   }
 }
 
@@ -304,10 +313,11 @@ extern "C" int sfvos_bn_eval_coeffs(const float* gamma, const float* beta, const
 }
 
 extern "C" int sfvos_bn_running_update(float* rm, float* rv, const float* means, const float* vars, int n,
-                                       int coef_stride, int C, float momentum, sfvos_stream_t stream) {
+                                       int coef_stride, int C, float momentum, int64_t* num_batches_tracked,
+                                       sfvos_stream_t stream) {
   SFVOS_REQUIRE(rm && rv && means && vars && n >= 0 && C > 0 && coef_stride >= C, "bn_running_update: bad argument");
   hipLaunchKernelGGL(bn_running_update_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, (hipStream_t)stream, rm, rv, means,
-                     vars, n, coef_stride, C, momentum);
+                     vars, n, coef_stride, C, momentum, (long long*)num_batches_tracked);
   return check_launch("bn_running_update");
 }
 
@@ -353,32 +363,35 @@ extern "C" int sfvos_bn_bwd_reduce(const void* dy, int ld_dy, const void* x, int
               hipLaunchKernelGGL((bn_bwd_kernel<SFVOS_F32, false>), dim3(grid), dim3(BNB_THREADS), 0, s,
                                  (const char*)dy, ld_dy, (const char*)x, ld_x, (char*)nullptr, 0, lt, C, scale, shift,
                                  mean, rstd, coef_stride, relu, (const float*)nullptr, (const float*)nullptr,
-                                 (const float*)nullptr, part),
+                                 (const float*)nullptr, part, (const float*)nullptr, (const float*)nullptr,
+                                 (float*)nullptr, (float*)nullptr, 0),
               hipLaunchKernelGGL((bn_bwd_kernel<SFVOS_BF16, false>), dim3(grid), dim3(BNB_THREADS), 0, s,
                                  (const char*)dy, ld_dy, (const char*)x, ld_x, (char*)nullptr, 0, lt, C, scale, shift,
                                  mean, rstd, coef_stride, relu, (const float*)nullptr, (const float*)nullptr,
-                                 (const float*)nullptr, part));
+                                 (const float*)nullptr, part, (const float*)nullptr, (const float*)nullptr,
+                                 (float*)nullptr, (float*)nullptr, 0));
   return check_launch("bn_bwd_reduce");
 }
 
 extern "C" int sfvos_bn_bwd_finalize(const float* part, const sfvos_levels* lv, const float* gamma, const float* mean,
-                                     const float* rstd, int coef_stride, int C, int train, int accumulate,
-                                     float* dgamma, float* dbeta, float* coefA, float* coefB, float* coefK,
-                                     sfvos_stream_t stream) {
+                                     const float* rstd, int coef_stride, int C, int train, float* coefA, float* coefB,
+                                     float* coefK, float* sum_dz, float* sum_dzx, sfvos_stream_t stream) {
   LevelTab lt;
   int rc = make_level_tab(lv, &lt, "bn_bwd_finalize");
   if (rc) return rc;
-  SFVOS_REQUIRE(part && gamma && mean && rstd && coefA && coefB && coefK, "bn_bwd_finalize: null pointer");
+  SFVOS_REQUIRE(part && gamma && mean && rstd && coefA && coefB && coefK && sum_dz && sum_dzx,
+                "bn_bwd_finalize: null pointer");
   SFVOS_REQUIRE(C > 0 && C % 32 == 0 && coef_stride >= C, "bn_bwd_finalize: bad C/coef_stride");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 32), dim3(32 * RL), 0, (hipStream_t)stream, part, lt, gamma,
-                     mean, rstd, coef_stride, C, train, accumulate, dgamma, dbeta, coefA, coefB, coefK);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C / 32, lt.n), dim3(32 * RL), 0, (hipStream_t)stream, part, lt, gamma,
+                     mean, rstd, coef_stride, C, train, coefA, coefB, coefK, sum_dz, sum_dzx);
   return check_launch("bn_bwd_finalize");
 }
 
 extern "C" int sfvos_bn_bwd_apply(const void* dy, int ld_dy, const void* x, int ld_x, void* dx, int ld_dx, int dtype,
                                   const sfvos_levels* lv, int C, const float* scale, const float* shift,
                                   int coef_stride, int relu, const float* coefA, const float* coefB,
-                                  const float* coefK, float* bias_part, sfvos_stream_t stream) {
+                                  const float* coefK, float* bias_part, const float* sum_dz, const float* sum_dzx,
+                                  float* dgamma, float* dbeta, int accumulate, sfvos_stream_t stream) {
   int rc = check_act("bn_bwd_apply", dtype, C, ld_dy, ld_x);
   if (rc) return rc;
   LevelTab lt;
@@ -387,16 +400,17 @@ extern "C" int sfvos_bn_bwd_apply(const void* dy, int ld_dy, const void* x, int 
   SFVOS_REQUIRE(dy && x && dx && scale && shift && coefA && coefB && coefK && coef_stride >= C,
                 "bn_bwd_apply: bad argument");
   SFVOS_REQUIRE(ld_dx >= C && ld_dx % (dtype == SFVOS_BF16 ? 8 : 4) == 0, "bn_bwd_apply: bad ld_dx");
+  SFVOS_REQUIRE(!(dgamma || dbeta) || (sum_dz && sum_dzx), "bn_bwd_apply: dgamma / dbeta need the per-level sums");
   const unsigned grid = (unsigned)lt.blk_begin[SFVOS_MAX_LEVELS];
   hipStream_t s = (hipStream_t)stream;
   DT_DISPATCH(dtype,
               hipLaunchKernelGGL((bn_bwd_kernel<SFVOS_F32, true>), dim3(grid), dim3(BNB_THREADS), 0, s,
                                  (const char*)dy, ld_dy, (const char*)x, ld_x, (char*)dx, ld_dx, lt, C, scale, shift,
                                  (const float*)nullptr, (const float*)nullptr, coef_stride, relu, coefA, coefB, coefK,
-                                 bias_part),
+                                 bias_part, sum_dz, sum_dzx, dgamma, dbeta, accumulate),
               hipLaunchKernelGGL((bn_bwd_kernel<SFVOS_BF16, true>), dim3(grid), dim3(BNB_THREADS), 0, s,
                                  (const char*)dy, ld_dy, (const char*)x, ld_x, (char*)dx, ld_dx, lt, C, scale, shift,
                                  (const float*)nullptr, (const float*)nullptr, coef_stride, relu, coefA, coefB, coefK,
-                                 bias_part));
+                                 bias_part, sum_dz, sum_dzx, dgamma, dbeta, accumulate));
   return check_launch("bn_bwd_apply");
 }

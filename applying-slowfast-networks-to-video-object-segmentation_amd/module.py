@@ -24,9 +24,9 @@ from .plan import SlowFastPlan
 _DT = {'fp32': (_lib.F32, torch.float32), 'bf16': (_lib.BF16, torch.bfloat16),
        # 'fp8': inference only; fast_conv1 (72 % of the forward FLOPs) runs on e4m3 operands, everything else as bf16
        'fp8': (_lib.BF16, torch.bfloat16)}
-# per-level coefficient rows of a BN layer: mean, rstd, scale, shift, var_unbiased, A, B, K
-_CF_ROWS = 8
-_MEAN, _RSTD, _SCALE, _SHIFT, _VARU, _CA, _CB, _CK = range(8)
+# per-level coefficient rows of a BN layer: mean, rstd, scale, shift, var_unbiased, A, B, K, sum dz, sum dz*xhat
+_CF_ROWS = 10
+_MEAN, _RSTD, _SCALE, _SHIFT, _VARU, _CA, _CB, _CK, _SDZ, _SDZX = range(10)
 
 
 def _ptr(t, elem_offset=0):
@@ -421,11 +421,12 @@ class SlowFastLayers(nn.Module):
                               _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), _ptr(cf[0, _VARU]), cs, st)
                     if bn.track_running_stats and bn.running_mean is not None:
                         # the reference runs the levels one after another: L consecutive momentum updates
-                        bn.num_batches_tracked.add_(L)
+                        # (num_batches_tracked += L in the same launch)
                         if bn.momentum is None:
                             raise RuntimeError('BatchNorm momentum=None (cumulative average) is not supported')
                         _lib.call('sfvos_bn_running_update', _ptr(bn.running_mean), _ptr(bn.running_var),
-                                  _ptr(cf[0, _MEAN]), _ptr(cf[0, _VARU]), L, cs, l.c_out, float(bn.momentum), st)
+                                  _ptr(cf[0, _MEAN]), _ptr(cf[0, _VARU]), L, cs, l.c_out, float(bn.momentum),
+                                  _ptr(bn.num_batches_tracked), st)
                 else:
                     with self._t('conv_fwd', l.name):
                         _lib.call('sfvos_conv3d', ctypes.byref(d), _ptr(src), _ptr(wp), bias, _ptr(raw), None, st)
@@ -585,12 +586,13 @@ class SlowFastLayers(nn.Module):
                           _ptr(cf[0, _RSTD]), cs, 1 if l.relu else 0, _ptr(w['part']), st)
                 _lib.call('sfvos_bn_bwd_finalize', _ptr(w['part']), ctypes.byref(lv), _ptr(bn.weight.detach()),
                           _ptr(cf[0, _MEAN]), _ptr(cf[0, _RSTD]), cs, l.c_out, 1 if state.train else 0,
-                          sacc if (l.bn + '.weight') in direct else 0, _ptr(w['dgamma']), _ptr(w['dbeta']), _ptr(cf[0, _CA]), _ptr(cf[0, _CB]), _ptr(cf[0, _CK]), st)
+                          _ptr(cf[0, _CA]), _ptr(cf[0, _CB]), _ptr(cf[0, _CK]), _ptr(cf[0, _SDZ]), _ptr(cf[0, _SDZX]), st)
                 grads[l.bn + '.weight'], grads[l.bn + '.bias'] = w['dgamma'], w['dbeta']
                 _lib.call('sfvos_bn_bwd_apply', _ptr(dy, l.dst_off), dy.shape[-1], _ptr(raw), l.c_out, _ptr(dx),
                           l.c_out, dt_id, ctypes.byref(lv), l.c_out, _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), cs,
                           1 if l.relu else 0, _ptr(cf[0, _CA]), _ptr(cf[0, _CB]), _ptr(cf[0, _CK]),
-                          _ptr(w['bpart']) if w['need_b'] else None, st)
+                          _ptr(w['bpart']) if w['need_b'] else None, _ptr(cf[0, _SDZ]), _ptr(cf[0, _SDZX]),
+                          _ptr(w['dgamma']), _ptr(w['dbeta']), sacc if (l.bn + '.weight') in direct else 0, st)
                 treg.__exit__(None, None, None)
                 if w['need_b']:
                     _lib.call('sfvos_reduce_rows', _ptr(w['bpart']), rows, l.c_out, _ptr(w['db']),

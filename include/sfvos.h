@@ -221,9 +221,11 @@ int sfvos_bn_eval_coeffs(const float* gamma, const float* beta, const float* run
                          float* shift, sfvos_stream_t stream);
 
 /* running = (1-momentum)*running + momentum*batch, applied for `n_updates` consecutive level rows
- * (means + l*coef_stride) in order: the reference updates once per FPN level (model.py:156-159). */
+ * (means + l*coef_stride) in order: the reference updates once per FPN level (model.py:156-159);
+ * num_batches_tracked (device int64 scalar, may be NULL) += n_updates. */
 int sfvos_bn_running_update(float* running_mean, float* running_var, const float* means, const float* vars_unbiased,
-                            int n_updates, int coef_stride, int C, float momentum, sfvos_stream_t stream);
+                            int n_updates, int coef_stride, int C, float momentum, int64_t* num_batches_tracked,
+                            sfvos_stream_t stream);
 
 /* y[m][0..C) = act(x[m][0..C) * scale_l + shift_l), act = ReLU when relu != 0 (model.py:114,122,...). */
 int sfvos_bn_apply(const void* x, int ld_x, void* y, int ld_y, int dtype, const sfvos_levels* lv, int C,
@@ -238,18 +240,21 @@ int sfvos_bn_bwd_reduce(const void* dy, int ld_dy, const void* x, int ld_x, int 
                         const float* scale, const float* shift, const float* mean, const float* rstd, int coef_stride,
                         int relu, float* part, sfvos_stream_t stream);
 
-/* Finish pass 1: dgamma (=|+=) sum_levels sum dz*xhat, dbeta (=|+=) sum_levels sum dz, and per level the three
- * coefficients of pass 2:  dx = A*dz + B*x + K.  train != 0: batch-stat backward; else eval
- * (A = gamma*rstd, B = K = 0). */
+/* Finish pass 1, all levels in parallel: per level the sums (sum_dz, sum_dzx: coefficient-table rows, level l at
+ * + l*coef_stride) and the three coefficients of pass 2:  dx = A*dz + B*x + K.  train != 0: batch-stat backward; else
+ * eval (A = gamma*rstd, B = K = 0). */
 int sfvos_bn_bwd_finalize(const float* part, const sfvos_levels* lv, const float* gamma, const float* mean,
-                          const float* rstd, int coef_stride, int C, int train, int accumulate, float* dgamma,
-                          float* dbeta, float* coefA, float* coefB, float* coefK, sfvos_stream_t stream);
+                          const float* rstd, int coef_stride, int C, int train, float* coefA, float* coefB,
+                          float* coefK, float* sum_dz, float* sum_dzx, sfvos_stream_t stream);
 
 /* Pass 2: dx[m][c] = A*dz + B*x + K (dz as in pass 1), stored as dtype with pitch ld_dx;
- * bias_part (may be NULL) receives per-block partial sums of dx: sfvos_bn_bwd_rows(lv) rows of [C]. */
+ * bias_part (may be NULL) receives per-block partial sums of dx: sfvos_bn_bwd_rows(lv) rows of [C];
+ * dgamma / dbeta (may be NULL) (=|+=) the per-level sums of pass 1 added in level order:
+ * dgamma = sum_l sum dz*xhat, dbeta = sum_l sum dz. */
 int sfvos_bn_bwd_apply(const void* dy, int ld_dy, const void* x, int ld_x, void* dx, int ld_dx, int dtype,
                        const sfvos_levels* lv, int C, const float* scale, const float* shift, int coef_stride,
                        int relu, const float* coefA, const float* coefB, const float* coefK, float* bias_part,
+                       const float* sum_dz, const float* sum_dzx, float* dgamma, float* dbeta, int accumulate,
                        sfvos_stream_t stream);
 
 /* out[c] (=|+=) sum_rows part[row][c]   (bias gradient from sfvos_bn_bwd_apply partials). */

@@ -386,8 +386,9 @@ def test_add_inplace_and_mse_loss(lib, prec):
 
 
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
-def test_layout_roundtrip_and_strided_source(lib, prec):
-    T, C, H, W = 5, 256, 7, 13
+@pytest.mark.parametrize('shape', [(5, 256, 7, 13), (3, 256, 8, 36), (2, 64, 12, 21)])   # odd planes / 16-byte-aligned planes
+def test_layout_roundtrip_and_strided_source(lib, prec, shape):
+    T, C, H, W = shape
     g = torch.Generator().manual_seed(3)
     frames = torch.randn(T, C, H, W, generator=g)
     # the reference hands over stack(frames).transpose(1, 2): a non-contiguous [C,T,H,W] view
@@ -447,16 +448,17 @@ def test_batchnorm_forward_backward_per_level(lib, prec, C, relu):
         ref_dx.append(xr.grad)
     # forward statistics from one "partial row" (sum, sumsq) per level
     part = torch.stack([torch.stack([x.double().sum(0), (x.double() ** 2).sum(0)]) for x in xs]).float().cuda()
-    cf = torch.zeros((L, 8, C), dtype=torch.float32, device='cuda')
-    cs = 8 * C
+    cf = torch.zeros((L, 10, C), dtype=torch.float32, device='cuda')
+    cs = 10 * C
     gd, bd = gamma.cuda(), beta.cuda()
     rows_pl = (ctypes.c_int * lib.MAX_LEVELS)(*([1] * L))
     lv = _levels(lib, ms)
     lib.call('sfvos_bn_finalize', P(part), L, rows_pl, lv.m, P(gd), P(bd), 1e-5, C, P(cf[0, 0]), P(cf[0, 1]),
              P(cf[0, 2]), P(cf[0, 3]), P(cf[0, 4]), cs, S())
     rmd, rvd = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
-    lib.call('sfvos_bn_running_update', P(rmd), P(rvd), P(cf[0, 0]), P(cf[0, 4]), L, cs, C, 0.1, S())
-    assert relmax(rmd.cpu(), rm) < 1e-5 and relmax(rvd.cpu(), rv) < 1e-5
+    nbt = torch.full((), 3, dtype=torch.int64, device='cuda')
+    lib.call('sfvos_bn_running_update', P(rmd), P(rvd), P(cf[0, 0]), P(cf[0, 4]), L, cs, C, 0.1, P(nbt), S())
+    assert relmax(rmd.cpu(), rm) < 1e-5 and relmax(rvd.cpu(), rv) < 1e-5 and int(nbt) == 3 + L
     ld = C + 32
     xd = torch.cat(xs).to(TDT[prec]).cuda()
     y = torch.full((M, ld), 9.0, dtype=TDT[prec], device='cuda')
@@ -471,14 +473,15 @@ def test_batchnorm_forward_backward_per_level(lib, prec, C, relu):
     bpart = torch.empty((rows, 2, C), dtype=torch.float32, device='cuda')
     lib.call('sfvos_bn_bwd_reduce', P(dyd, 32), ld, P(xd), C, dt, ctypes.byref(lv), C, P(cf[0, 2]), P(cf[0, 3]),
              P(cf[0, 0]), P(cf[0, 1]), cs, relu, P(bpart), S())
-    dg, db = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
-    lib.call('sfvos_bn_bwd_finalize', P(bpart), ctypes.byref(lv), P(gd), P(cf[0, 0]), P(cf[0, 1]), cs, C, 1, 0, P(dg),
-             P(db), P(cf[0, 5]), P(cf[0, 6]), P(cf[0, 7]), S())
-    assert relmax(dg.cpu(), gr.grad) < 1e-4 and relmax(db.cpu(), br.grad) < 1e-4
+    dg, db = torch.full((C,), 2.0, device='cuda'), torch.full((C,), -1.0, device='cuda')
+    lib.call('sfvos_bn_bwd_finalize', P(bpart), ctypes.byref(lv), P(gd), P(cf[0, 0]), P(cf[0, 1]), cs, C, 1,
+             P(cf[0, 5]), P(cf[0, 6]), P(cf[0, 7]), P(cf[0, 8]), P(cf[0, 9]), S())
     dx = torch.empty((M, C), dtype=TDT[prec], device='cuda')
     biasp = torch.empty((rows, C), dtype=torch.float32, device='cuda')
     lib.call('sfvos_bn_bwd_apply', P(dyd, 32), ld, P(xd), C, P(dx), C, dt, ctypes.byref(lv), C, P(cf[0, 2]),
-             P(cf[0, 3]), cs, relu, P(cf[0, 5]), P(cf[0, 6]), P(cf[0, 7]), P(biasp), S())
+             P(cf[0, 3]), cs, relu, P(cf[0, 5]), P(cf[0, 6]), P(cf[0, 7]), P(biasp), P(cf[0, 8]), P(cf[0, 9]), P(dg),
+             P(db), 1, S())   # accumulate: dgamma / dbeta are ADDED to what the buffers held
+    assert relmax(dg.cpu() - 2.0, gr.grad) < 1e-4 and relmax(db.cpu() + 1.0, br.grad) < 1e-4
     assert relmax(dx.float().cpu(), torch.cat(ref_dx)) < (1e-4 if prec == 'fp32' else 1e-2)
     dbias = torch.empty(C, device='cuda')
     lib.call('sfvos_reduce_rows', P(biasp), rows, C, P(dbias), 0, S())
