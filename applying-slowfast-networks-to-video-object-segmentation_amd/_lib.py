@@ -89,6 +89,7 @@ SIGNATURES = {
     'sfvos_bn_eval_coeffs': (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp]),
     'sfvos_bn_running_update': (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp, vp]),
     'sfvos_bn_apply': (i32, [vp, i32, vp, i32, i32, PL, i32, vp, vp, i32, i32, vp]),
+    'sfvos_bn_apply_fp8': (i32, [vp, i32, vp, i32, PL, i32, vp, vp, i32, i32, f32, vp, vp]),
     'sfvos_bn_bwd_rows': (i32, [PL]),
     'sfvos_bn_bwd_reduce': (i32, [vp, i32, vp, i32, i32, PL, i32, vp, vp, vp, vp, i32, i32, vp, vp]),
     'sfvos_bn_bwd_finalize': (i32, [vp, PL, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),

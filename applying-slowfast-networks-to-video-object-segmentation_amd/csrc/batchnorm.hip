@@ -127,6 +127,38 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* __restrict__ 
   }
 }
 
+// y = sat_e4m3(act(x * scale + shift) * act_scale): the slow pathway's concat buffers as e4m3 operands of the next
+// 3x3 conv (BASELINE config 5).  x: bf16 [M][ld_x]; y: bytes [M][ld_y]; 16 channels (one 16-byte chunk) per lane.
+__global__ __launch_bounds__(256) void bn_apply_fp8_kernel(const char* __restrict__ x, int ld_x, char* y, int ld_y,
+                                                           LevelTab lt, int C, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int cs, int relu,
+                                                           float act_scale, int* sat_count) {
+  const int cpr = C / 16;
+  const long long total = lt.mb[SFVOS_MAX_LEVELS] * cpr;
+  int sat = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long m = i / cpr;
+    const int c = (int)(i - m * cpr) * 16;
+    const long long co = (long long)level_of_pos(lt, m) * cs + c;
+    float f[16];
+    unpack<SFVOS_BF16>(*(const u32x4*)(x + (m * ld_x + c) * 2), f);
+    unpack<SFVOS_BF16>(*(const u32x4*)(x + (m * ld_x + c + 8) * 2), f + 8);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      float v = f[e] * scale[co + e] + shift[co + e];
+      v = (relu ? fmaxf(v, 0.f) : v) * act_scale;
+      sat += fabsf(v) > 448.f ? 1 : 0;
+      f[e] = v;
+    }
+    *(u32x4*)(y + m * ld_y + c) = pack<SFVOS_FP8>(f);
+  }
+  if (sat_count != nullptr) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sat += __shfl_xor(sat, o);
+    if ((threadIdx.x & 63) == 0 && sat > 0) atomicAdd(sat_count, sat);
+  }
+}
+
 // BN backward pass 1 / pass 2 share the thread layout: a block belongs to ONE level and owns a
 // strided set of 512-position runs of it; thread = (chunk of CE channels, row lane); per-channel
 // partials reduced through LDS in a fixed order -> one deterministic partial row per block.
@@ -339,6 +371,22 @@ extern "C" int sfvos_bn_apply(const void* x, int ld_x, void* y, int ld_y, int dt
               hipLaunchKernelGGL(bn_apply_kernel<SFVOS_BF16>, dim3(grid), dim3(256), 0, s, (const char*)x, ld_x,
                                  (char*)y, ld_y, lt, C, scale, shift, coef_stride, relu));
   return check_launch("bn_apply");
+}
+
+extern "C" int sfvos_bn_apply_fp8(const void* x, int ld_x, void* y, int ld_y, const sfvos_levels* lv, int C,
+                                  const float* scale, const float* shift, int coef_stride, int relu, float act_scale,
+                                  int* sat_count, sfvos_stream_t stream) {
+  LevelTab lt;
+  int rc = make_level_tab(lv, &lt, "bn_apply_fp8");
+  if (rc) return rc;
+  SFVOS_REQUIRE(x && y && scale && shift && coef_stride >= C && act_scale > 0.f, "bn_apply_fp8: bad argument");
+  SFVOS_REQUIRE(C > 0 && C % 16 == 0 && ld_x >= C && ld_x % 8 == 0 && ld_y >= C && ld_y % 16 == 0 &&
+                    (((size_t)y) & 15) == 0,
+                "bn_apply_fp8: C must be a multiple of 16, ld_x of 8 (bf16), ld_y of 16 (bytes), y 16-byte aligned");
+  const unsigned grid = grid_for(lt.mb[SFVOS_MAX_LEVELS] * (C / 16), 256 * 4);
+  hipLaunchKernelGGL(bn_apply_fp8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const char*)x, ld_x, (char*)y,
+                     ld_y, lt, C, scale, shift, coef_stride, relu, act_scale, sat_count);
+  return check_launch("bn_apply_fp8");
 }
 
 extern "C" int sfvos_bn_bwd_rows(const sfvos_levels* lv) {

@@ -107,8 +107,13 @@ struct ConvCfg {
 template <int DT, int TAPS, int TPS, int TT, int MT, int NT, int WS, int WN, int CIN>
 __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
   typedef ConvCfg<DT, TAPS, TPS, TT, MT, NT, WS, WN> C;
-  typedef typename Elt<DT>::type T;
-  constexpr int CE = Elt<DT>::CE, CK = 4 * CE;
+  // F8 (e4m3 operands, SFVOS_FP8): a 16-byte chunk holds 16 channels, a pixel's 64-byte group 64; one
+  // v_mfma_scale_f32_32x32x64_f8f6f4 consumes the whole group (chunks hh and 2+hh per lane half), so a tap is ONE
+  // k-step instead of two; results leave as bf16, de-quantised per output channel (as in the frame-split kernel).
+  constexpr bool F8 = DT == SFVOS_FP8;
+  constexpr int YDT = YOf<DT>::DTY;
+  typedef typename Elt<YDT>::type T;   // element type of y
+  constexpr int CE = Elt<DT>::CE, CEY = Elt<YDT>::CE, CK = 4 * CE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ring = smem;
   char* const wbase = smem + C::R * C::X_BYTES;
@@ -241,29 +246,50 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
     // k-step k = (tap_local, st): a PD-deep register pipeline -- the fragments of step k+PD-1 are read
     // from LDS while the MFMAs of step k run, so the wait in front of a step never covers reads that
     // were issued just before it (counted lgkmcnt, not lgkmcnt(0)).
-    constexpr int PD = (WS * WN == 4 || TT * MT * NT * 16 + 3 * (NT + TT * MT) * 4 <= 192) ? 3 : 2;  // registers
-    constexpr int KS = 2 * TPS;
+    constexpr int OPR = F8 ? 8 : 4;  // registers per operand fragment
+    constexpr int PD = (!F8 && (WS * WN == 4 || TT * MT * NT * 16 + 3 * (NT + TT * MT) * OPR <= 192)) ? 3 : 2;  // registers
+    constexpr int KS = F8 ? TPS : 2 * TPS;
     constexpr int PPS = (NPIECE + KS - 1) / KS;  // DMA pieces per k-step
-    u32x4 bv[PD][NT], av[PD][TT][MT];
+    u32x4 bv[F8 ? 1 : PD][NT], av[F8 ? 1 : PD][TT][MT];
+    i32x8 bv8[F8 ? PD : 1][NT], av8[F8 ? PD : 1][TT][MT];
+    auto read8 = [&](const char* lo, const char* hi) {
+      const i32x4 l = __builtin_bit_cast(i32x4, lds_read16(lo)), h = __builtin_bit_cast(i32x4, lds_read16(hi));
+      return __builtin_shufflevector(l, h, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
     auto load = [&](int k, int buf) {
 #ifdef SFVOS_ABLATE  // timing-only builds (scratch): 1 = no A re-reads, 2 = no B re-reads, 3 = neither
       const bool skip_a = (SFVOS_ABLATE & 1) && k > 1, skip_b = (SFVOS_ABLATE & 2) && k > 1;
 #else
       constexpr bool skip_a = false, skip_b = false;
 #endif
-      const int tp = k >> 1, st = k & 1;
+      const int tp = F8 ? k : k >> 1, st = F8 ? 0 : k & 1;
       // 3x3: a tap group is one kernel row (TPS == 3): dh = tg (runtime), dw = tp (compile-time, indexes xsw)
       static_assert(TAPS == 1 || TPS == 3, "3x3 layers stage one kernel row per tap group");
       const int dh = (TAPS == 9) ? tg : 0, dw = (TAPS == 9) ? tp : 0;
+      if constexpr (F8) {
 #pragma unroll
-      for (int q = 0; q < NT; ++q)
-        if (!skip_b) bv[buf][q] = lds_read16(wbl + ((tp * 4 + 2 * st) * C::BN + q * 32) * 16);
+        for (int q = 0; q < NT; ++q) {
+          const char* wt = wbl + (tp * 4 * C::BN + q * 32) * 16;
+          bv8[buf][q] = read8(wt, wt + 2 * C::BN * 16);
+        }
 #pragma unroll
-      for (int j = 0; j < TT; ++j)
+        for (int j = 0; j < TT; ++j)
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-          if (!skip_a)
-            av[buf][j][i] = lds_read16(xfl[j] + xsw[st][dw] + (i + dh) * C::HC * 64);
+          for (int i = 0; i < MT; ++i) {
+            const char* xr = xfl[j] + (i + dh) * C::HC * 64;
+            av8[buf][j][i] = read8(xr + xsw[0][dw], xr + xsw[1][dw]);
+          }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NT; ++q)
+          if (!skip_b) bv[buf][q] = lds_read16(wbl + ((tp * 4 + 2 * st) * C::BN + q * 32) * 16);
+#pragma unroll
+        for (int j = 0; j < TT; ++j)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            if (!skip_a)
+              av[buf][j][i] = lds_read16(xfl[j] + xsw[st][dw] + (i + dh) * C::HC * 64);
+      }
     };
 #pragma unroll
     for (int k = 0; k < PD - 1 && k < KS; ++k) load(k, k % PD);
@@ -278,7 +304,13 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int q = 0; q < NT; ++q) Mma<DT>::run(acc[j][i][q], av[k % PD][j][i], bv[k % PD][q]);
+          for (int q = 0; q < NT; ++q) {
+            if constexpr (F8)  // e4m3 x e4m3, block scales 2^0 (E8M0 127): the real scales are applied in the epilogue
+              acc[j][i][q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av8[k % PD][j][i], bv8[k % PD][q],
+                                                                              acc[j][i][q], 0, 0, 0, 127, 0, 127);
+            else
+              Mma<F8 ? SFVOS_BF16 : DT>::run(acc[j][i][q], av[k % PD][j][i], bv[k % PD][q]);
+          }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < PPS; ++u)
@@ -348,12 +380,13 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
   const long long yfs = a.lv.yfs[lvl];
   __syncthreads();  // every wave has finished reading the ring / weight buffers
   float* scr = (float*)smem + wv * (32 * 33);  // [32 px][32 ch], rows padded to 33 floats
-  constexpr int CPP = 32 / CE;                  // 16-byte output chunks per pixel of a tile
+  constexpr int CPP = 32 / CEY;                 // 16-byte output chunks per pixel of a tile
 #pragma unroll
   for (int q = 0; q < NT; ++q) {
     const int nbase = n0 + (wn * NT + q) * 32;
     if (nbase >= a.c_out) continue;  // wave-uniform
     const float bias = a.bias ? a.bias[nbase + r] : 0.f;
+    const float desc = F8 ? a.bias[a.c_out + nbase + r] : 1.f;  // e4m3: [2][c_out] = (bias, de-quantisation factor)
 #pragma unroll
     for (int j = 0; j < TT; ++j) {
       const int to = tb0 + j;
@@ -365,7 +398,7 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int px = (e & 3) + 8 * (e >> 2) + 4 * hh;
-          float v = acc[j][i][q][e] + bias;
+          float v = F8 ? acc[j][i][q][e] * desc + bias : acc[j][i][q][e] + bias;
           if (a.relu) v = fmaxf(v, 0.f);
           scr[px * 33 + r] = v;
           if (w0 + px < W) { s1[q] += v; s2[q] += v * v; }
@@ -373,22 +406,22 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
         T* yrow = yclip + (to * yfs + (long long)h * W + w0) * a.ld_y + nbase;
 #pragma unroll
         for (int it = 0; it < (32 * CPP) / 64; ++it) {
-          const int idx = it * 64 + lane, px = idx / CPP, ch = (idx % CPP) * CE;
-          float f[CE];
+          const int idx = it * 64 + lane, px = idx / CPP, ch = (idx % CPP) * CEY;
+          float f[CEY];
 #pragma unroll
-          for (int u = 0; u < CE; ++u) f[u] = scr[px * 33 + ch + u];
+          for (int u = 0; u < CEY; ++u) f[u] = scr[px * 33 + ch + u];
           if (w0 + px < W) {
             T* dst = yrow + (long long)px * a.ld_y + ch;
             if (a.accumulate) {
               const u32x4 old = *(const u32x4*)dst;
-              T oldv[CE];
+              T oldv[CEY];
               __builtin_memcpy(oldv, &old, 16);
 #pragma unroll
-              for (int u = 0; u < CE; ++u) f[u] += Elt<DT>::to_f32(oldv[u]);
+              for (int u = 0; u < CEY; ++u) f[u] += Elt<YDT>::to_f32(oldv[u]);
             }
-            T outv[CE];
+            T outv[CEY];
 #pragma unroll
-            for (int u = 0; u < CE; ++u) outv[u] = Elt<DT>::from_f32(f[u]);
+            for (int u = 0; u < CEY; ++u) outv[u] = Elt<YDT>::from_f32(f[u]);
             u32x4 o;
             __builtin_memcpy(&o, outv, 16);
             *(u32x4*)dst = o;
@@ -1035,8 +1068,8 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
   SFVOS_REQUIRE(d->pad_t >= 0 && d->pad_t < d->kt + 1, "conv: bad pad_t %d", d->pad_t);
   const int ce = d->dtype == SFVOS_BF16 ? 8 : d->dtype == SFVOS_FP8 ? 16 : 4;
   if (d->dtype == SFVOS_FP8)
-    SFVOS_REQUIRE(d->taps == 9 && d->c_out <= 32 && d->c_in % 64 == 0 && d->accumulate == 0,
-                  "conv: e4m3 operands are implemented for the 3x3 layers with c_out <= 32 (c_in %% 64 == 0) only");
+    SFVOS_REQUIRE(d->taps == 9 && d->c_in % 64 == 0 && d->accumulate == 0 && d->pad_t == 0,
+                  "conv: e4m3 operands are implemented for forward 3x3 convs with c_in %% 64 == 0 (no accumulate)");
   SFVOS_REQUIRE(d->ld_y >= d->c_out, "conv: pitch smaller than channel count");
   SFVOS_REQUIRE(d->x_frame_stride >= 0 && d->y_frame_stride >= 0, "conv: negative frame stride");
   if (d->x_group_stride != 0) {
@@ -1064,7 +1097,10 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
     p->family = 1; split_frames(p->t_out, 3, p); p->MT = 2; p->NT = 2 / WNW; p->TH = 8; p->BN = 64;
   } else {
     // accumulators: TT x MT x NT tiles of 16 registers per wave: at most 9 tiles per wave
-    p->family = 2; p->NT = (d->c_out <= 192 ? 6 : 8) / WNW; split_frames(p->t_out, p->NT == 3 ? 3 : 2, p);
+    // (e4m3 operand fragments are 8 registers each: 128 output channels per workgroup and at most two frames per
+    // block there -- the wider tiles spill)
+    p->family = 2; p->NT = d->dtype == SFVOS_FP8 ? 2 : (d->c_out <= 192 ? 6 : 8) / WNW;
+    split_frames(p->t_out, d->dtype == SFVOS_FP8 ? 2 : (p->NT == 3 ? 3 : 2), p);
     p->MT = 1; p->TH = 4;
     p->BN = 32 * p->NT * WNW;
     // Data-gradient convs (pad_t = kt-1): most (output frame, temporal tap) pairs of a multi-frame block meet only
@@ -1147,7 +1183,8 @@ static int launch_fs(const ConvArgs& a, long long grid, hipStream_t stream) {
 template <int DT, int TAPS>
 static int dispatch(const ConvPlan& p, const ConvArgs& a, long long grid, hipStream_t s) {
 #define SFVOS_CASE(F, TPSv, TTv, MTv, NTv, WSv, WNv) \
-  if (p.family == F && p.TT == TTv && p.MT == MTv && p.NT == NTv) return launch<DT, TAPS, TPSv, TTv, MTv, NTv, WSv, WNv>(a, grid, s);
+  if constexpr ((DT == SFVOS_FP8) == ((NTv) == 2 && (F) == 2))                                                        \
+    if (p.family == F && p.TT == TTv && p.MT == MTv && p.NT == NTv) return launch<DT, TAPS, TPSv, TTv, MTv, NTv, WSv, WNv>(a, grid, s);
   // two waves per SIMD
   if constexpr (TAPS == 1) {
     // narrow 1x1 (lateral data gradient 64 -> 32): 8 rows x 32 px x TT frames x 32 channels; wave = one row
@@ -1161,6 +1198,8 @@ static int dispatch(const ConvPlan& p, const ConvArgs& a, long long grid, hipStr
     SFVOS_CASE(2, 3, 1, 1, 4, 4, 2) SFVOS_CASE(2, 3, 2, 1, 4, 4, 2)
     // single-frame blocks (data gradients): 8 rows x 32 px x 192/256 channels, two rows per wave
     SFVOS_CASE(2, 3, 1, 2, 3, 4, 2) SFVOS_CASE(2, 3, 1, 2, 4, 4, 2)
+    // e4m3 operands: 4 rows x 32 px x TT frames x 128 channels
+    SFVOS_CASE(2, 3, 1, 1, 2, 4, 2) SFVOS_CASE(2, 3, 2, 1, 2, 4, 2)
   }
 #undef SFVOS_CASE
   set_error("conv: no kernel instance for family %d TT %d MT %d NT %d taps %d", p.family, p.TT, p.MT, p.NT, TAPS);
@@ -1249,6 +1288,8 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
     SFVOS_REQUIRE(grid > 0 && grid < (1ll << 31), "conv: grid %lld out of range", grid);
     if (d->dtype == SFVOS_BF16)
       rc = d->taps == 9 ? dispatch<SFVOS_BF16, 9>(p, a, grid, s) : dispatch<SFVOS_BF16, 1>(p, a, grid, s);
+    else if (d->dtype == SFVOS_FP8)
+      rc = dispatch<SFVOS_FP8, 9>(p, a, grid, s);   // make_plan admits e4m3 for 3x3 convs only
     else
       rc = d->taps == 9 ? dispatch<SFVOS_F32, 9>(p, a, grid, s) : dispatch<SFVOS_F32, 1>(p, a, grid, s);
     if (rc != SFVOS_OK) return rc;

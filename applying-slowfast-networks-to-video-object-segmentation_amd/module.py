@@ -22,7 +22,8 @@ from . import _lib
 from .plan import SlowFastPlan
 
 _DT = {'fp32': (_lib.F32, torch.float32), 'bf16': (_lib.BF16, torch.bfloat16),
-       # 'fp8': inference only; fast_conv1 (72 % of the forward FLOPs) runs on e4m3 operands, everything else as bf16
+       # 'fp8': inference only; the four Cin = 256 convs (fast_conv1, slow_conv1-3: 99 % of the forward FLOPs) run on
+       # e4m3 operands, the 32-channel layers and every conv RESULT stay bf16
        'fp8': (_lib.BF16, torch.bfloat16)}
 # per-level coefficient rows of a BN layer: mean, rstd, scale, shift, var_unbiased, A, B, K, sum dz, sum dz*xhat
 _CF_ROWS = 10
@@ -191,6 +192,7 @@ class SlowFastLayers(nn.Module):
         if self.precision not in _DT:
             raise ValueError("precision must be 'fp32', 'bf16' or 'fp8', got %r" % (self.precision,))
         self.fp8_input_scale = 32.0   # e4m3 activation scale of the input clip (|x| * scale must stay below 448)
+        self.fp8_act_scale = 32.0     # ... of the slow pathway's concat buffers (post-ReLU BatchNorm outputs)
         self._fp8_sat = None          # device int: input elements that saturated in e4m3 since the last check
         self._packs = {}     # (conv name, kind, dtype) -> ((param version, data_ptr, epoch), packed tensor)
         self._timer = None
@@ -264,11 +266,12 @@ class SlowFastLayers(nn.Module):
         self._packs[key] = (tag, packed)
         return packed
 
-    def _packed_fp8(self, layer):
-        """(e4m3 weight image, [3][c_out] (bias, descale, weight scale) rows) of a 3x3 layer, cached like _packed."""
+    def _packed_fp8(self, layer, act_scale):
+        """(e4m3 weight image, [3][c_out] (bias, descale, weight scale) rows) of a 3x3 layer whose input was quantised
+        with act_scale, cached like _packed."""
         conv = getattr(self, layer.conv)
         w = conv.weight
-        key = (layer.conv, 'fwd8', float(self.fp8_input_scale))
+        key = (layer.conv, 'fwd8', float(act_scale))
         hit = self._packs.get(key)
         tag = (w._version, w.data_ptr(), _lib.weight_epoch(), None if conv.bias is None else conv.bias._version)
         if hit is not None and hit[0] == tag:
@@ -280,7 +283,7 @@ class SlowFastLayers(nn.Module):
             wc = wc.float().contiguous()
         bc = None if conv.bias is None else conv.bias.detach().float().contiguous()
         _lib.call('sfvos_pack_weights_fp8', _ptr(wc), _ptr(bc) if bc is not None else None, _ptr(packed), _ptr(bd),
-                  layer.c_out, layer.c_in, layer.kt, layer.taps, float(self.fp8_input_scale), _stream())
+                  layer.c_out, layer.c_in, layer.kt, layer.taps, float(act_scale), _stream())
         self._packs[key] = (tag, (packed, bd))
         return packed, bd
 
@@ -289,8 +292,8 @@ class SlowFastLayers(nn.Module):
         d = _lib.ConvDesc()
         d.x_group_stride = d.x_frame_stride = d.y_frame_stride = 0
         if torch.is_tensor(ld_x):
-            if ld_x.dim() == 3:
-                d.x_group_stride, ld_x = ld_x.shape[1] * 32, 32
+            if ld_x.dim() == 3:   # channel-group-major: [C/32][M][32] bf16 or [C/64][M][64] e4m3
+                d.x_group_stride, ld_x = ld_x.shape[1] * ld_x.shape[2], ld_x.shape[2]
             else:
                 ld_x = ld_x.shape[-1]
         d.dtype, d.batch, d.kt, d.taps, d.pyr = dt_id, B, layer.kt, layer.taps, pyr
@@ -359,18 +362,23 @@ class SlowFastLayers(nn.Module):
         # image packed, BEFORE the side stream is forked, and nothing is freed until the streams are joined,
         # so the caching allocator never hands memory still in use on one stream to the other.
         work = {}
+        # e4m3 path: the Cin = 256 3x3 convs take e4m3 operands -- the input clip (64-channel groups) and the slow
+        # pathway's concat buffers, which BN-apply writes as e4m3 [M][256] directly; conv results stay bf16
+        fp8_bufs = ('cat1', 'cat2') if fp8 else ()
+        if fp8 and (self._fp8_sat is None or self._fp8_sat.device != dev):
+            self._fp8_sat = torch.zeros(1, dtype=torch.int32, device=dev)
         for l in plan.layers:
             for name in (l.raw, l.dst):
                 if name not in bufs:
                     b = plan.buffers[name]
-                    bufs[name] = torch.empty((B * b.frames * pix, b.channels), dtype=tdt, device=dev)
+                    bufs[name] = torch.empty((B * b.frames * pix, b.channels),
+                                             dtype=torch.uint8 if name in fp8_bufs else tdt, device=dev)
             sname, t_alloc, t_off = self._src_window(l, slow_offset, x_frames, x_pad)
             src = bufs[sname]
             lv = _lib.make_levels(shapes, B, l.t_out)
-            if fp8 and l.name == 'f1':   # e4m3 operands: x = [C/64][M][64] bytes, (bias, descale) rows as `bias`
-                d = self._desc(l, B, pyr, _lib.FP8, 64, l.c_out)
-                d.x_group_stride = src.shape[1] * 64
-                wp, bd = self._packed_fp8(l)
+            if fp8 and l.taps == 9 and l.c_in % 64 == 0:   # (bias, descale) rows travel as `bias`
+                d = self._desc(l, B, pyr, _lib.FP8, src, l.c_out, t_alloc, t_off)
+                wp, bd = self._packed_fp8(l, self.fp8_input_scale if sname == 'xf0' else self.fp8_act_scale)
                 w = dict(d=d, lv=lv, src=src, wp=wp, bias8=bd,
                          cf=torch.empty((L, _CF_ROWS, l.c_out), dtype=torch.float32, device=dev))
             else:
@@ -436,9 +444,14 @@ class SlowFastLayers(nn.Module):
                     if L > 1:
                         cf[1:, :4] = cf[0, :4]  # same running statistics for every level (plumbing copy)
                 with self._t('bn_apply', l.name):
-                    _lib.call('sfvos_bn_apply', _ptr(raw), l.c_out, _ptr(dst, l.dst_off), dst.shape[-1], dt_id,
-                              ctypes.byref(lv), l.c_out, _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), cs,
-                              1 if l.relu else 0, st)
+                    if l.dst in fp8_bufs:
+                        _lib.call('sfvos_bn_apply_fp8', _ptr(raw), l.c_out, _ptr(dst, l.dst_off), dst.shape[-1],
+                                  ctypes.byref(lv), l.c_out, _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), cs,
+                                  1 if l.relu else 0, float(self.fp8_act_scale), _ptr(self._fp8_sat), st)
+                    else:
+                        _lib.call('sfvos_bn_apply', _ptr(raw), l.c_out, _ptr(dst, l.dst_off), dst.shape[-1], dt_id,
+                                  ctypes.byref(lv), l.c_out, _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), cs,
+                                  1 if l.relu else 0, st)
                 if side is not None and l.name in ('f1', 'f2'):
                     ev[l.name] = torch.cuda.Event()
                     ev[l.name].record(stream)
@@ -721,8 +734,12 @@ class SlowFastLayers(nn.Module):
         slow_features = {k: [dic[k] for dic in slow_features] for k in slow_features[0]}
         fast_features = {k: [dic[k] for dic in fast_features] for k in fast_features[0]}
         keys = list(slow_features.keys())
-        slow_list = [torch.stack(slow_features[k]).to(self.device).transpose(1, 2) for k in keys]
-        fast_list = [torch.stack(fast_features[k]).to(self.device).transpose(1, 2) for k in keys]
+        # model.py:157-158 stacks the B per-clip tensors; the reference always passes B = 1, where the stack is a pure
+        # copy of the whole clip (2.8 GB read + 2.8 GB written at fp=32): a view of the caller's tensor does the same
+        def batch(ts):
+            return (ts[0].to(self.device).unsqueeze(0) if len(ts) == 1 else torch.stack(ts).to(self.device)).transpose(1, 2)
+        slow_list = [batch(slow_features[k]) for k in keys]
+        fast_list = [batch(fast_features[k]) for k in keys]
         merged = self._run(slow_list, fast_list)
         return OrderedDict(zip(keys, merged))
 
@@ -768,10 +785,9 @@ class _SlowFastPyramidFn(torch.autograd.Function):
             shapes = [tuple(f.shape[3:]) for f in fast_list]
             slow_offset = module._slow_alias_offset(slow_list, fast_list)
             if module.precision == 'fp8':
-                # the fast clip as e4m3 (read by fast_conv1 only); the few slow frames separately as bf16
+                # the fast clip as e4m3 64-channel groups, read by fast_conv1 and (its centre frames) by slow_conv1
                 xf0 = module._to_pyramid_fp8(fast_list, module.plan.fp)
-                xs0 = module._to_pyramid(slow_list, module.plan.sp, dt_id, tdt)
-                slow_offset = None
+                xs0 = None if slow_offset is not None else module._to_pyramid_fp8(slow_list, module.plan.sp)
             else:
                 xf0 = module._to_pyramid(fast_list, module.plan.fp, dt_id, tdt)
                 xs0 = None if slow_offset is not None else module._to_pyramid(slow_list, module.plan.sp, dt_id, tdt)

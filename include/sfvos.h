@@ -145,7 +145,7 @@ int sfvos_pack_weights_fp8(const float* w, const float* bias, void* packed, floa
 typedef struct sfvos_conv_desc {
   int struct_size; /* = sizeof(sfvos_conv_desc) of the binder's mirror; every entry point taking a desc rejects a mismatch */
   int dtype;       /* SFVOS_F32: f32 storage, exact-f32 MFMA; SFVOS_BF16: bf16 storage, f32 accumulate;
-                    * SFVOS_FP8 (sfvos_conv3d only, 3x3 layers with c_out <= 32): x and the weight image are OCP e4m3
+                    * SFVOS_FP8 (sfvos_conv3d only, forward 3x3 layers with c_in a multiple of 64): x and the weight image are OCP e4m3
                     * (x in 64-channel = 64-byte groups: x_group_stride > 0 counted in elements = bytes, or plain NDHWC
                     * with ld_x a multiple of 64), products on v_mfma_scale_f32_32x32x64_f8f6f4 (2x the bf16 rate),
                     * f32 accumulate, y stored as bf16; `bias` then points to [2][c_out] floats: row 0 the bias, row 1
@@ -230,6 +230,13 @@ int sfvos_bn_running_update(float* running_mean, float* running_var, const float
 /* y[m][0..C) = act(x[m][0..C) * scale_l + shift_l), act = ReLU when relu != 0 (model.py:114,122,...). */
 int sfvos_bn_apply(const void* x, int ld_x, void* y, int ld_y, int dtype, const sfvos_levels* lv, int C,
                    const float* scale, const float* shift, int coef_stride, int relu, sfvos_stream_t stream);
+
+/* The same with an e4m3 result (BASELINE config 5: the activation becomes the e4m3 operand of the next 3x3 conv):
+ * y[m][c] = sat_e4m3(act(x*scale_l + shift_l) * act_scale); x bf16 with pitch ld_x (elements), y bytes with pitch ld_y;
+ * C a multiple of 16; sat_count (device int, may be NULL) += values beyond +-448 before saturation. */
+int sfvos_bn_apply_fp8(const void* x, int ld_x, void* y, int ld_y, const sfvos_levels* lv, int C, const float* scale,
+                       const float* shift, int coef_stride, int relu, float act_scale, int* sat_count,
+                       sfvos_stream_t stream);
 
 /* Rows of partials sfvos_bn_bwd_reduce / _apply write for these levels (level-major). */
 int sfvos_bn_bwd_rows(const sfvos_levels* lv);

@@ -490,6 +490,62 @@ def test_batchnorm_forward_backward_per_level(lib, prec, C, relu):
         assert relmax(dbias.cpu() + 1.0, dx.float().sum(0).cpu() + 1.0) < 1e-3
 
 
+def test_bn_apply_fp8_feeds_an_e4m3_conv_in_ndhwc(lib):
+    """sfvos_bn_apply_fp8 writes act(x*scale+shift)*act_scale as e4m3 into a channel slice of an [M][256]-byte buffer
+    (the slow pathway's concat), and sfvos_conv3d reads that buffer as plain-NDHWC e4m3 operands (ld_x = 256 bytes)."""
+    g = torch.Generator().manual_seed(31)
+    B, T, shapes, C = 1, 3, [(7, 19), (4, 6)], 256
+    ms = [B * T * H * W for H, W in shapes]
+    M = sum(ms)
+    lv = _levels(lib, ms)
+    x = torch.randn(M, C, generator=g).bfloat16()
+    scale = torch.rand(len(shapes), 10, C, generator=g) + 0.5
+    shift = torch.randn(len(shapes), 10, C, generator=g) * 0.3
+    cf = torch.zeros(len(shapes), 10, C)
+    cf[:, 2], cf[:, 3] = scale[:, 2], shift[:, 3]
+    cfd, xd = cf.cuda(), x.cuda()
+    act = 32.0
+    y = torch.full((M, C), 0x7f, dtype=torch.uint8, device='cuda')
+    sat = torch.zeros(1, dtype=torch.int32, device='cuda')
+    # two channel slices, as slow_conv (192) and the lateral (64) write them
+    for c0, cn in ((0, 192), (192, 64)):
+        xs_ = xd[:, c0:c0 + cn].contiguous()
+        lib.call('sfvos_bn_apply_fp8', P(xs_), cn, P(y, c0), C, ctypes.byref(lv), cn, P(cfd[0, 2], c0), P(cfd[0, 3], c0),
+                 10 * C, 1, act, P(sat), S())
+    f8 = torch.float8_e4m3fn
+    lvl = torch.cat([torch.full((m,), i) for i, m in enumerate(ms)])
+    ref = torch.relu(x.float() * cf[lvl, 2] + cf[lvl, 3]) * act
+    want = ref.clamp(max=448.0).to(f8)
+    gotq = y.cpu().view(f8).float()
+    diff = gotq != want.float()   # an fma in the kernel may round a tie the other way: at most one e4m3 step, rarely
+    assert float(diff.float().mean()) < 1e-3
+    assert float(((gotq - want.float()).abs() / want.float().abs().clamp_min(2.0 ** -9)).max()) <= 0.126
+    assert abs(int(sat) - int((ref > 448.0).sum())) <= 2
+    # the e4m3 buffer as the x operand of a wide 3x3 conv
+    cout, kt = 192, 2
+    w = torch.randn(cout, C, kt, 3, 3, generator=g) / np.sqrt(C * kt * 9)
+    wp = torch.empty(w.numel(), dtype=torch.uint8, device='cuda')
+    bd = torch.empty((3, cout), dtype=torch.float32, device='cuda')
+    w_dev = w.cuda()
+    lib.call('sfvos_pack_weights_fp8', P(w_dev), None, P(wp), P(bd), cout, C, kt, 9, act, S())
+    d, t_out = make_desc(lib, 'bf16', B, T, shapes, C, cout, kt, 9, 0, C, cout)
+    d.dtype = lib.FP8
+    Mo = sum(B * t_out * H * W for H, W in shapes)
+    out = torch.zeros((Mo, cout), dtype=torch.bfloat16, device='cuda')
+    lib.call('sfvos_conv3d', ctypes.byref(d), P(y), P(wp), P(bd), P(out), None, S())
+    ws = 448.0 / w.abs().amax(dim=(1, 2, 3, 4))
+    wq = (w * ws[:, None, None, None, None]).to(f8).float() / ws[:, None, None, None, None]
+    xq = gotq / act
+    off = 0
+    xs5 = []
+    for (H, W), m in zip(shapes, ms):
+        xs5.append(xq[off:off + m].reshape(B, T, H, W, C).permute(0, 4, 1, 2, 3))
+        off += m
+    refs = [F.conv3d(v, wq, None, padding=(0, 1, 1)) for v in xs5]
+    for a, r in zip(from_pyr(out, B, cout, t_out, shapes), refs):
+        assert relmax(a, r) < 1e-2
+
+
 def test_sgd_step_and_scale(lib):
     n = 100003
     g = torch.Generator().manual_seed(5)
@@ -538,11 +594,15 @@ def test_mask_union_matches_the_reference_numpy_loop(lib, n):
 
 
 @pytest.mark.parametrize('case', [(1, 6, [(12, 21), (5, 9)], 256, 32, 3), (2, 5, [(9, 17)], 64, 32, 2),
-                                  (1, 14, [(10, 33)], 128, 32, 11)])
+                                  (1, 14, [(10, 33)], 128, 32, 11),
+                                  # the wide kernel (slow pathway): 192 / 224 / 256 output channels, 1-3 output frames
+                                  (1, 4, [(12, 21), (6, 10)], 256, 192, 2), (1, 2, [(9, 35)], 256, 224, 2),
+                                  (2, 3, [(6, 10), (3, 5)], 128, 256, 2)])
 def test_conv3d_fp8_operands_match_a_dequantised_reference(lib, case):
-    """SFVOS_FP8 (first step of BASELINE config 5): e4m3 x (64-channel groups) and e4m3 weight image with
-    per-output-channel scales, f32 accumulate, bf16 result.  The reference convolves the SAME quantised values
-    (torch.float8_e4m3fn round trip) in fp32, so only summation order and the bf16 store differ: 1e-2."""
+    """SFVOS_FP8 (BASELINE config 5): e4m3 x (64-channel groups) and e4m3 weight image with per-output-channel scales,
+    f32 accumulate, bf16 result -- the frame-split kernel (c_out 32) and the wide kernel (c_out 192-256).  The
+    reference convolves the SAME quantised values (torch.float8_e4m3fn round trip) in fp32, so only summation order
+    and the bf16 store differ: 1e-2."""
     B, T, shapes, cin, cout, kt = case
     g = torch.Generator().manual_seed(77)
     w = torch.randn(cout, cin, kt, 3, 3, generator=g) / np.sqrt(cin * kt * 9)

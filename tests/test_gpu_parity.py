@@ -592,11 +592,12 @@ def test_batch_of_two_clips_equals_two_single_clip_calls_in_eval(precision):
 
 @pytest.mark.parametrize('sp,fp', [(3, 7), (4, 32)])
 def test_fp8_inference_path_error_is_measured_and_bounded(sp, fp):
-    """precision='fp8' (BASELINE config 5, first step: fast_conv1 on e4m3 operands, inference only): the tolerance is
-    RE-STATED FROM MEASUREMENT, not assumed -- rel-L2 and argmax agreement of the fused maps against the fp32 oracle
-    are printed (measured: rel-L2 0.019 of the fused map, 0.027-0.030 on the fast-pathway channels, bf16 0.005; argmax
-    agreement 0.97-1.00); the gates sit above the measurement: rel-L2 < 0.05, argmax agreement >= 0.95.
-    Training / autograd state is refused."""
+    """precision='fp8' (BASELINE config 5, inference only): the four Cin = 256 convs (fast_conv1, slow_conv1-3 = 99 % of
+    the forward FLOPs) on e4m3 operands -- input clip quantised per tensor (scale 32), weights per output channel, the
+    slow pathway's concat buffers written as e4m3 by BN-apply (scale 32), f32 accumulate, bf16 results.  The tolerance
+    is RE-STATED FROM MEASUREMENT, not assumed: rel-L2 and argmax agreement of the fused maps against the fp32 oracle
+    are printed; the gates sit above the measurement: rel-L2 < 0.08, argmax agreement >= 0.90.  No input element may
+    saturate at these scales.  Training / autograd state is refused."""
     m8, dev = build(sp, fp, 'fp8')
     mb, _ = build(sp, fp, 'bf16')
     m8.eval(); mb.eval()
@@ -617,7 +618,8 @@ def test_fp8_inference_path_error_is_measured_and_bounded(sp, fp):
         agree = float((a8.argmax(1) == r.argmax(1)).float().mean())
         print('(%d,%d) level %s: fp8 rel-L2 %.4f (fast channels %.4f), bf16 rel-L2 %.4f, argmax agreement fp8 %.3f'
               % (sp, fp, k, l2_8, fast_8, l2_b, agree))
-        assert fast_8 < 0.05 and l2_8 < 0.05 and agree >= 0.95
+        assert fast_8 < 0.08 and l2_8 < 0.08 and agree >= 0.90
+    assert m8.fp8_saturated() == 0
     m8.train()
     with pytest.raises(RuntimeError):
         m8.temporally_enhance_features(slow, fast)
