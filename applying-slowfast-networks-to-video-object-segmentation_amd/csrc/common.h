@@ -123,6 +123,11 @@ struct LdsAttrOnce {
 
 // lateral.hip: dedicated kernel for the lateral (k x 1 x 1) data gradient; -1 = shape not covered
 int lateral_dgrad_try(const sfvos_conv_desc* d, const void* x, const void* w_packed, void* y, hipStream_t stream);
+// ... and for its forward (32 -> 64 channels): shape test, statistics rows (= workgroups) of a level, launch
+bool lateral_fwd_applies(const sfvos_conv_desc* d);
+int lateral_fwd_rows(const sfvos_conv_desc* d, int level);
+int lateral_fwd_launch(const sfvos_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
+                       float* stat_part, hipStream_t stream);
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

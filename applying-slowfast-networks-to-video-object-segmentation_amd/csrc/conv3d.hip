@@ -966,7 +966,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_fs_kernel(ConvArgs a) {
 
 // ---- host-side planning ----------------------------------------------------------------------------
 struct ConvPlan {
-  int family;  // 0 narrow 1x1 (c_out <= 32), 1 mid (c_out == 64, 1x1), 2 wide, 3 frame-split (c_out <= 32, 3x3)
+  int family;  // 0 narrow 1x1 (c_out <= 32), 1 mid (c_out == 64, 1x1), 2 wide, 3 frame-split (c_out <= 32, 3x3),
+               // 4 lateral forward (lateral.hip: its own kernel, one statistics row per workgroup)
   int TT, MT, NT, TH, BN;
   int t_blocks, n_blocks, t_out;  // t_blocks = total frame blocks
   int n_launch, l_tt[3], l_blocks[3], l_first[3];  // launches: blocks of l_tt frames starting at frame l_first
@@ -1086,7 +1087,13 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
   SFVOS_REQUIRE(p->t_out >= 1, "conv: kernel longer than padded input (t_in %d, kt %d, pad_t %d)", d->t_in, d->kt,
                 d->pad_t);
   constexpr int WNW = 2;  // waves across the channel dimension (mid / wide families)
-  if (d->c_out <= 32 && d->taps == 9) {
+  bool lateral_ok = true;
+#ifdef SFVOS_DIAG
+  lateral_ok = !getenv("SFVOS_NO_LATERAL_KERNEL");
+#endif
+  if (lateral_ok && lateral_fwd_applies(d)) {
+    p->family = 4; split_frames(p->t_out, 3, p); p->MT = 1; p->NT = 1; p->TH = 8; p->BN = 64;
+  } else if (d->c_out <= 32 && d->taps == 9) {
     long long units = 0;
     for (int l = 0; l < d->pyr.n_levels && l < SFVOS_MAX_LEVELS; ++l)
       units += (long long)d->batch * ceil_div(d->pyr.h[l] > 0 ? d->pyr.h[l] : 1, 8) * ceil_div(d->pyr.w[l] > 0 ? d->pyr.w[l] : 1, 32);
@@ -1156,6 +1163,13 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
   }
   lv.wg_begin[SFVOS_MAX_LEVELS] = (int)wg;
   lv.row_begin[SFVOS_MAX_LEVELS] = (int)rows;
+  if (p->family == 4) {  // rows are the workgroups of the lateral kernel
+    rows = 0;
+    for (int l = 0; l <= SFVOS_MAX_LEVELS; ++l) {
+      lv.row_begin[l] = (int)rows;
+      if (l < lv.n) rows += lateral_fwd_rows(d, l);
+    }
+  }
   return SFVOS_OK;
 }
 
@@ -1238,6 +1252,7 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
     rc = lateral_dgrad_try(d, x, w_packed, y, (hipStream_t)stream);  // lateral data gradient: its own HBM-bound kernel
     if (rc >= 0) return rc;
   }
+  if (p.family == 4) return lateral_fwd_launch(d, x, w_packed, bias, y, stat_part, (hipStream_t)stream);
   ConvArgs a;
   a.x = (const char*)x; a.wp = (const char*)w_packed; a.bias = bias; a.y = (char*)y; a.stat_part = stat_part;
   a.batch = d->batch; a.t_in = d->t_in; a.t_alloc = d->t_alloc; a.t_offset = d->t_offset; a.t_out = p.t_out;

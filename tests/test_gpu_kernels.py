@@ -79,6 +79,10 @@ CONV_CASES = [
     (1, 9, [(18, 16), (4, 35)], 32, 64, 5, 1),     # lateral, t_out 5
     (1, 5, [(7, 40)], 32, 64, 3, 1),
     (1, 3, [(10, 12), (3, 3)], 64, 32, 2, 1),      # lateral dgrad shape (narrow, 1x1)
+    # lateral forward with t_out <= 3 (bf16: the dedicated kernel of lateral.hip; fp32: generic)
+    (2, 21, [(9, 13), (3, 3), (1, 2)], 32, 64, 20, 1),   # t_out 2, kt 20, ragged tiles and idle waves
+    (1, 8, [(16, 33)], 32, 64, 8, 1),                    # t_out 1
+    (1, 22, [(24, 42), (12, 21), (6, 11)], 32, 64, 20, 1),  # t_out 3: the first lateral of cfg (2,1,4)
 ]
 
 
@@ -117,6 +121,27 @@ def test_conv3d_forward_bias_stats(lib, prec, case):
         assert float((s[0] - ref.double().sum((0, 2, 3, 4))).abs().max()) / n < 1e-3 * float(ref.abs().max())
         assert relmax(s[1], (ref.double() ** 2).sum((0, 2, 3, 4))) < (1e-4 if prec == 'fp32' else 2e-2)
     assert torch.all(y[:, cout:].float() == -3.0), 'wrote outside its channel slice'
+
+
+def test_lateral_forward_window_and_relu_epilogue(lib):
+    """lateral forward kernel (lateral.hip): frames [t_offset, t_offset + t_in) of a longer buffer, no bias, ReLU."""
+    B, Ta, T, off, shapes, kt = 2, 9, 6, 2, [(5, 21), (2, 3)], 4
+    g = torch.Generator().manual_seed(77)
+    w = (torch.randn(64, 32, kt, 1, 1, generator=g) / np.sqrt(32 * kt)).bfloat16().float()
+    xs = [torch.randn(B, 32, Ta, H, W, generator=g).bfloat16().float() for (H, W) in shapes]
+    refs = [F.relu(F.conv3d(x[:, :, off:off + T], w, None)) for x in xs]
+    xd = to_pyr(xs, 'bf16', 40)
+    d, t_out = make_desc(lib, 'bf16', B, T, shapes, 32, 64, kt, 1, 0, 40, 64, t_alloc=Ta, t_offset=off)
+    d.relu = 1
+    wp = torch.empty(w.numel(), dtype=torch.bfloat16, device='cuda')
+    lib.call('sfvos_pack_weights_fwd', P(w.cuda()), P(wp), d.dtype, 64, 32, kt, 1, S())
+    M = sum(B * t_out * H * W for H, W in shapes)
+    y = torch.full((M, 64), -3.0, dtype=torch.bfloat16, device='cuda')
+    lib.call('sfvos_conv3d', ctypes.byref(d), P(xd), P(wp), None, P(y), None, S())
+    torch.cuda.synchronize()
+    got = from_pyr(y, B, 64, t_out, shapes)
+    for l, ref in enumerate(refs):
+        assert relmax(got[l], ref) < TOL['bf16'], 'level %d' % l
 
 
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])

@@ -133,6 +133,9 @@ if which == 'f1f8':
     conv('f1 256->32 k11', 32, 256, 32, 11, 9, reps=reps)
 if which in ('all', 'wf1'):
     wgrad('f1 256->32 k11', 32, 256, 32, 11, 9, reps=reps)
+if which == 'latf':
+    conv('l1 32->64 k20', 22, 32, 64, 20, 1, reps=reps)
+    conv('l2 32->64 k11', 12, 32, 64, 11, 1, reps=reps)
 if which == 'lat':
     conv('dgrad l1 64->32 k20', 3, 64, 32, 20, 1, pad_t=19, reps=reps, acc=1)
     conv('dgrad l2 64->32 k11', 2, 64, 32, 11, 1, pad_t=10, reps=reps, acc=1)
