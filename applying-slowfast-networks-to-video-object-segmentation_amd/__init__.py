@@ -10,9 +10,9 @@ from .optim import FusedSGD  # noqa: F401
 from .losses import MSEProxyLoss  # noqa: F401
 from .stream import SlowFastStream  # noqa: F401
 from .mask_head import (MaskBranch, MaskRCNNHeads, MaskRCNNPredictor, maskrcnn_inference,  # noqa: F401
-                        paste_masks_in_image)
+                        maskrcnn_loss, paste_masks_in_image)
 from .parallel import GradBucket, init_distributed  # noqa: F401
 
 __all__ = ['SlowFastLayers', 'PackedClip', 'SlowFastPlan', 'FusedSGD', 'GradBucket', 'init_distributed',
            'MSEProxyLoss', 'calc_kernel_sizes', 'calc_fuse_kernel_size', 'davis_pyramid', 'union_mask', 'SlowFastStream', 'MaskBranch', 'MaskRCNNHeads', 'MaskRCNNPredictor',
-           'maskrcnn_inference', 'paste_masks_in_image']
+           'maskrcnn_inference', 'maskrcnn_loss', 'paste_masks_in_image']

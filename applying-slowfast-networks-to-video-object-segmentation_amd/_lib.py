@@ -106,6 +106,16 @@ SIGNATURES = {
     'sfvos_deconv2x2_relu': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'sfvos_mask_logits': (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
     'sfvos_paste_masks': (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    'sfvos_relu_bwd_rows': (i32, [i64]),
+    'sfvos_relu_bwd': (i32, [vp, vp, vp, i32, i64, i32, vp, vp]),
+    'sfvos_mask_bce_loss': (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
+    'sfvos_mask_bce_loss_grad': (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    'sfvos_mask_logits_bwd_rows': (i32, [i32, i32]),
+    'sfvos_mask_logits_bwd': (i32, [vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+    'sfvos_pack_deconv2x2_dgrad': (i32, [vp, vp, i32, i32, i32, vp]),
+    'sfvos_deconv2x2_dgrad': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    'sfvos_deconv2x2_wgrad_workspace_bytes': (C.c_size_t, [i32, i32, i32, i32, i32]),
+    'sfvos_deconv2x2_wgrad': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
 }
 
 _lib = None

@@ -10,7 +10,12 @@ torchvision is third-party, not vendored and absent in this build's environment,
 published module structure (same attribute names and state-dict keys, so that the slices
 `roi_heads.mask_head.*` / `roi_heads.mask_predictor.*` of a reference checkpoint load with strict=True) and their
 results are checked against a torch-core restatement (oracle/mask_head_ref.py) -- PARITY UNPINNED BY THE REFERENCE.
-RoIAlign itself stays torchvision's (out of scope).  Forward / inference only; no CPU fallback."""
+RoIAlign itself stays torchvision's (out of scope).  No CPU fallback.
+
+Training: the reference trains roi_heads (only backbone and RPN are frozen, model.py:176-179; losses.backward() at
+model.py:369).  `MaskBranch.forward` is differentiable (w.r.t. the RoI features and all 12 parameters) through one
+autograd Function whose backward runs on libsfvos kernels, and `maskrcnn_loss` is torchvision's mask loss behind the
+RoIAlign of the ground-truth masks (the caller passes the [N,28,28] targets)."""
 import ctypes
 
 import torch
@@ -66,38 +71,37 @@ class MaskRCNNHeads(nn.Module):
                 nn.init.kaiming_normal_(p, mode='fan_out', nonlinearity='relu')
         self._packs = {}
 
-    def _packed(self, conv, dt_id, tdt):
+    def _packed(self, conv, dt_id, tdt, dgrad=False):
         w = conv.weight
-        key = id(conv)
+        key = (id(conv), dgrad)
         tag = (w._version, w.data_ptr(), dt_id)
         hit = self._packs.get(key)
         if hit is not None and hit[0] == tag:
             return hit[1]
         wc = w.detach().float().contiguous()
         packed = torch.empty(wc.numel(), dtype=tdt, device=w.device)
-        _lib.call('sfvos_pack_weights_fwd', _ptr(wc), _ptr(packed), dt_id, conv.out_channels, conv.in_channels, 1, 9,
-                  _stream())
+        _lib.call('sfvos_pack_weights_dgrad' if dgrad else 'sfvos_pack_weights_fwd', _ptr(wc), _ptr(packed), dt_id,
+                  conv.out_channels, conv.in_channels, 1, 9, _stream())
         self._packs[key] = (tag, packed)
         return packed
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, keep=False):
+        """keep: return every activation [input, after mask_fcn1 + ReLU, ...] (channels-last) for the backward."""
         _check_gpu(x, 'MaskRCNNHeads')
         dt_id, tdt = _DT[self.precision]
         N, C, H, W = x.shape
         cur = _to_nhwc(x.detach(), dt_id, tdt)
-        pyr = _lib.make_pyramid([(H, W)])
+        acts = [cur]
         for i in range(1, self.n_layers + 1):
             conv = getattr(self, 'mask_fcn%d' % i)
-            d = _lib.ConvDesc()
-            d.dtype, d.batch, d.t_in, d.t_alloc, d.t_offset = dt_id, N, 1, 1, 0
-            d.c_in, d.c_out, d.kt, d.taps, d.pad_t = conv.in_channels, conv.out_channels, 1, 9, 0
-            d.ld_x, d.ld_y, d.accumulate, d.relu, d.pyr = conv.in_channels, conv.out_channels, 0, 1, pyr
+            d = _conv_desc(dt_id, N, H, W, conv.in_channels, conv.out_channels, 1)
             y = torch.empty((N, H, W, conv.out_channels), dtype=tdt, device=x.device)
             bias = _ptr(conv.bias.detach()) if conv.bias is not None else None
             _lib.call('sfvos_conv3d', ctypes.byref(d), _ptr(cur), _ptr(self._packed(conv, dt_id, tdt)), bias, _ptr(y),
                       None, _stream())
             cur = y
-        return cur
+            acts.append(cur)
+        return acts if keep else cur
 
     def forward(self, x):
         dt_id, _ = _DT[self.precision]
@@ -120,6 +124,7 @@ class MaskRCNNPredictor(nn.Module):
             if 'weight' in name:
                 nn.init.kaiming_normal_(p, mode='fan_out', nonlinearity='relu')
         self._pack = None
+        self._pack_d = None
 
     def _deconv_nhwc(self, x_nhwc):
         dt_id, tdt = _DT[self.precision]
@@ -136,6 +141,16 @@ class MaskRCNNPredictor(nn.Module):
         _lib.call('sfvos_deconv2x2_relu', _ptr(x_nhwc), _ptr(self._pack[1]), _ptr(b.detach()) if b is not None else None,
                   _ptr(y), dt_id, N, H, W, w.shape[0], w.shape[1], 1, _stream())
         return y
+
+    def _packed_dgrad(self, dt_id, tdt):
+        w = self.conv5_mask.weight
+        tag = (w._version, w.data_ptr(), dt_id)
+        if self._pack_d is None or self._pack_d[0] != tag:
+            wc = w.detach().float().contiguous()
+            packed = torch.empty(wc.numel(), dtype=tdt, device=w.device)
+            _lib.call('sfvos_pack_deconv2x2_dgrad', _ptr(wc), _ptr(packed), dt_id, w.shape[0], w.shape[1], _stream())
+            self._pack_d = (tag, packed)
+        return self._pack_d[1]
 
     def _logits(self, y_nhwc, labels=None, want_logits=True, want_prob=False):
         dt_id, _ = _DT[self.precision]
@@ -193,6 +208,133 @@ def paste_masks_in_image(masks, boxes, img_shape, padding=1):
     return out
 
 
+def _conv_desc(dt_id, N, H, W, c_in, c_out, relu):
+    d = _lib.ConvDesc()
+    d.dtype, d.batch, d.t_in, d.t_alloc, d.t_offset = dt_id, N, 1, 1, 0
+    d.c_in, d.c_out, d.kt, d.taps, d.pad_t = c_in, c_out, 1, 9, 0
+    d.ld_x, d.ld_y, d.accumulate, d.relu, d.pyr = c_in, c_out, 0, relu, _lib.make_pyramid([(H, W)])
+    return d
+
+
+class _MaskBranchFn(torch.autograd.Function):
+    """RoI features [N,256,H,W] -> mask logits [N,K,2H,2W], keeping the channels-last activations for the backward.
+    Parameter order: mask_fcn{1..L}.(weight, bias), conv5_mask.(weight, bias), mask_fcn_logits.(weight, bias)."""
+
+    @staticmethod
+    def forward(ctx, branch, x, *params):
+        head, pred = branch.mask_head, branch.mask_predictor
+        acts = head.forward_nhwc(x, keep=True)                 # [a0 (input), a1, ..., aL] NHWC, post-ReLU
+        y5 = pred._deconv_nhwc(acts[-1])
+        logits, _ = pred._logits(y5)
+        ctx.branch, ctx.acts, ctx.y5 = branch, acts, y5
+        ctx.shape = tuple(x.shape)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        branch, acts, y5 = ctx.branch, ctx.acts, ctx.y5
+        head, pred = branch.mask_head, branch.mask_predictor
+        dt_id, tdt = _DT[head.precision]
+        dev = y5.device
+        N, _, H, W = ctx.shape
+        f32 = dict(dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad     # (branch, x, *params)
+        grads = []
+        # ---- mask_fcn_logits + the ReLU in front of it
+        conv = pred.mask_fcn_logits
+        K, C = conv.out_channels, conv.in_channels
+        P2 = 4 * H * W
+        dl = dlogits.detach().float().contiguous()
+        rows = _lib.load().sfvos_mask_logits_bwd_rows(N, P2)
+        L = K * C + K + C
+        part = torch.empty((rows, L), **f32)
+        dz = torch.empty_like(y5)
+        wl = conv.weight.detach().float().reshape(K, C).contiguous()
+        _lib.call('sfvos_mask_logits_bwd', _ptr(y5), dt_id, _ptr(dl), _ptr(wl), N, P2, C, K, 1, _ptr(dz), _ptr(part),
+                  _stream())
+        comb = torch.empty(L, **f32)
+        _lib.call('sfvos_reduce_rows', _ptr(part), rows, L, _ptr(comb), 0, _stream())
+        g_wl, g_bl, g_b5 = comb[:K * C].view(K, C, 1, 1), comb[K * C:K * C + K], comb[K * C + K:]
+        # ---- conv5_mask (ConvTranspose2d 2x2 s2)
+        w5 = pred.conv5_mask.weight
+        ci5, co5 = w5.shape[0], w5.shape[1]
+        g_w5 = torch.empty(w5.shape, **f32)
+        ws = torch.empty(_lib.load().sfvos_deconv2x2_wgrad_workspace_bytes(N, H, W, ci5, co5), dtype=torch.uint8,
+                         device=dev)
+        _lib.call('sfvos_deconv2x2_wgrad', _ptr(acts[-1]), _ptr(dz), dt_id, N, H, W, ci5, co5, _ptr(g_w5), 0, _ptr(ws),
+                  _stream())
+        cur = torch.empty_like(acts[-1])
+        _lib.call('sfvos_deconv2x2_dgrad', _ptr(dz), _ptr(pred._packed_dgrad(dt_id, tdt)), _ptr(cur), dt_id, N, H, W,
+                  ci5, co5, _stream())
+        tail = [g_w5, g_b5, g_wl, g_bl]
+        # ---- mask_fcn{L..1}: ReLU backward (+ bias gradient), weight gradient, data gradient
+        M = N * H * W
+        lib = _lib.load()
+        conv_grads = []
+        for i in range(head.n_layers, 0, -1):
+            conv = getattr(head, 'mask_fcn%d' % i)
+            cin, cout = conv.in_channels, conv.out_channels
+            rrows = lib.sfvos_relu_bwd_rows(M)
+            rpart = torch.empty((rrows, cout), **f32)
+            _lib.call('sfvos_relu_bwd', _ptr(cur), _ptr(acts[i]), _ptr(cur), dt_id, M, cout, _ptr(rpart), _stream())
+            g_b = torch.empty(cout, **f32)
+            _lib.call('sfvos_reduce_rows', _ptr(rpart), rrows, cout, _ptr(g_b), 0, _stream())
+            d = _conv_desc(dt_id, N, H, W, cin, cout, 0)
+            g_w = torch.empty(conv.weight.shape, **f32)
+            wsz = lib.sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
+            wws = torch.empty(max(int(wsz), 16), dtype=torch.uint8, device=dev)
+            _lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), _ptr(acts[i - 1]), _ptr(cur), _ptr(g_w), 0, _ptr(wws),
+                      _stream())
+            conv_grads.append((g_w, g_b))
+            if i > 1 or need[1]:
+                dd = _conv_desc(dt_id, N, H, W, cout, cin, 0)
+                nxt = torch.empty((N, H, W, cin), dtype=tdt, device=dev)
+                _lib.call('sfvos_conv3d', ctypes.byref(dd), _ptr(cur), _ptr(head._packed(conv, dt_id, tdt, dgrad=True)),
+                          None, _ptr(nxt), None, _stream())
+                cur = nxt
+        dx = _to_nchw(cur, dt_id) if need[1] else None
+        for g_w, g_b in reversed(conv_grads):
+            grads += [g_w, g_b]
+        grads += tail
+        return (None, dx) + tuple(g if n else None for g, n in zip(grads, need[2:]))
+
+
+class _MaskLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, targets):
+        N, K = logits.shape[0], logits.shape[1]
+        P = logits[0, 0].numel()
+        lg = logits.detach().float().contiguous()
+        lab = labels.to(device=lg.device, dtype=torch.int64).contiguous()
+        tg = targets.detach().to(device=lg.device, dtype=torch.float32).contiguous()
+        if lab.numel() != N or tg.numel() != N * P:
+            raise RuntimeError('maskrcnn_loss: one label and one [M,M] target per RoI expected')
+        loss = torch.empty((), dtype=torch.float32, device=lg.device)
+        _lib.call('sfvos_mask_bce_loss', _ptr(lg), _ptr(lab), _ptr(tg), N, K, P, _ptr(loss), _stream())
+        ctx.save_for_backward(lg, lab, tg)
+        return loss
+
+    @staticmethod
+    def backward(ctx, up):
+        lg, lab, tg = ctx.saved_tensors
+        N, K = lg.shape[0], lg.shape[1]
+        P = lg[0, 0].numel()
+        upc = up.detach().float().contiguous()
+        d = torch.empty_like(lg)
+        _lib.call('sfvos_mask_bce_loss_grad', _ptr(lg), _ptr(lab), _ptr(tg), _ptr(upc), N, K, P, _ptr(d), _stream())
+        return d, None, None
+
+
+def maskrcnn_loss(mask_logits, labels, mask_targets):
+    """torchvision roi_heads.maskrcnn_loss behind `project_masks_on_boxes` (the RoIAlign of the ground-truth masks is
+    torchvision's): mean binary cross-entropy with logits between the label's channel of `mask_logits` [N,K,M,M] and
+    `mask_targets` [N,M,M]; `mask_logits.sum() * 0` when there is no positive RoI."""
+    if mask_logits.shape[0] == 0 or mask_targets.numel() == 0:
+        return mask_logits.sum() * 0
+    _check_gpu(mask_logits, 'maskrcnn_loss')
+    return _MaskLossFn.apply(mask_logits, labels, mask_targets)
+
+
 class MaskBranch(nn.Module):
     """mask_head + mask_predictor as the reference's roi_heads holds them (attribute names = torchvision's, so
     `load_state_dict` takes the `roi_heads.` slice of a reference checkpoint)."""
@@ -202,8 +344,23 @@ class MaskBranch(nn.Module):
         self.mask_head = MaskRCNNHeads(in_channels, (256, 256, 256, 256), 1, precision)
         self.mask_predictor = MaskRCNNPredictor(256, 256, num_classes, precision)   # model.py:20-25
 
+    def _ordered_params(self):
+        ps = []
+        for i in range(1, self.mask_head.n_layers + 1):
+            conv = getattr(self.mask_head, 'mask_fcn%d' % i)
+            ps += [conv.weight, conv.bias]
+        ps += [self.mask_predictor.conv5_mask.weight, self.mask_predictor.conv5_mask.bias,
+               self.mask_predictor.mask_fcn_logits.weight, self.mask_predictor.mask_fcn_logits.bias]
+        return ps
+
     def forward(self, roi_features):
-        """RoIAligned features [N,256,14,14] -> mask logits [N,num_classes,28,28] (training-side output)."""
+        """RoIAligned features [N,256,14,14] -> mask logits [N,num_classes,28,28] (training-side output);
+        differentiable w.r.t. the features and the parameters (backward on libsfvos kernels)."""
+        ps = self._ordered_params()
+        if torch.is_grad_enabled() and roi_features.shape[0] > 0 and \
+                (roi_features.requires_grad or any(p.requires_grad for p in ps)):
+            _check_gpu(roi_features, 'MaskBranch')
+            return _MaskBranchFn.apply(self, roi_features, *ps)
         return self.mask_predictor.forward_from_nhwc(self.mask_head.forward_nhwc(roi_features))[0]
 
     @torch.no_grad()

@@ -323,6 +323,48 @@ int sfvos_mask_logits(const void* x, int dtype, const float* w, const float* bia
 int sfvos_paste_masks(const float* masks, const float* boxes, int n, int mask_size, int padding, int img_h, int img_w,
                       float* out, sfvos_stream_t stream);
 
+/* ---- training side of the mask branch (the reference trains roi_heads: only backbone and RPN are frozen,
+ * model.py:176-179; losses.backward() at model.py:369 runs through torchvision's maskrcnn_loss and these modules).
+ * The 3x3 convs: sfvos_conv3d with a sfvos_pack_weights_dgrad image (data gradient) and sfvos_conv3d_wgrad. ---- */
+
+/* ReLU backward + bias gradient partials: dz[m][c] = a[m][c] > 0 ? dy[m][c] : 0 (a == NULL: dz = dy; dz may alias dy or
+ * be NULL); col_part (may be NULL): sfvos_relu_bwd_rows(m) rows of [c] fp32, row r = column sums of dz over its 64
+ * positions (sum them with sfvos_reduce_rows: the bias gradient of the conv that produced a).  dy, a, dz: [m][c] dtype. */
+int sfvos_relu_bwd_rows(int64_t m);
+int sfvos_relu_bwd(const void* dy, const void* a, void* dz, int dtype, int64_t m, int c, float* col_part,
+                   sfvos_stream_t stream);
+
+/* torchvision roi_heads.maskrcnn_loss behind the RoIAlign of the ground-truth masks:
+ * loss[0] = mean_{n,p} BCEWithLogits(logits[n][labels[n]][p], targets[n][p]); logits [n][num_classes][positions] fp32,
+ * targets [n][positions] fp32, labels int64; reduced in a fixed order (f64). */
+int sfvos_mask_bce_loss(const float* logits, const int64_t* labels, const float* targets, int n, int num_classes,
+                        int positions, float* loss, sfvos_stream_t stream);
+/* dlogits[n][k][p] = k == labels[n] ? upstream * (sigmoid(logit) - target) / (n * positions) : 0;
+ * upstream: device scalar (autograd's grad_output) or NULL for 1. */
+int sfvos_mask_bce_loss_grad(const float* logits, const int64_t* labels, const float* targets, const float* upstream,
+                             int n, int num_classes, int positions, float* dlogits, sfvos_stream_t stream);
+
+/* Backward of mask_fcn_logits (conv1x1 c -> num_classes) and of the ReLU in front of it.  y: the deconv's post-ReLU
+ * output, NHWC [n][positions][c] dtype; dlogits [n][num_classes][positions] fp32; w [num_classes][c] fp32.
+ * dz[n][p][c] = (relu == 0 || y > 0) ? sum_k dlogits[n][k][p] w[k][c] : 0   (dtype, same shape as y);
+ * part: sfvos_mask_logits_bwd_rows(n, positions) rows of [num_classes*c + num_classes + c] fp32 =
+ * (grad of w | grad of the logits bias | column sums of dz = grad of the deconv bias) partials (sfvos_reduce_rows). */
+int sfvos_mask_logits_bwd_rows(int n, int positions);
+int sfvos_mask_logits_bwd(const void* y, int dtype, const float* dlogits, const float* w, int n, int positions, int c,
+                          int num_classes, int relu, void* dz, float* part, sfvos_stream_t stream);
+
+/* ConvTranspose2d(Cin, Cout, 2, 2, 0) backward.  Data gradient: weight [Cin][Cout][2][2] fp32 -> packed image, then
+ * dx[n][i][j][ci] = sum_{a,b,co} dz[n][2i+a][2j+b][co] w[ci][co][a][b]; dz NHWC [n][2h][2w][c_out], dx NHWC
+ * [n][h][w][c_in], both dtype. */
+int sfvos_pack_deconv2x2_dgrad(const float* w, void* packed, int dtype, int c_in, int c_out, sfvos_stream_t stream);
+int sfvos_deconv2x2_dgrad(const void* dz, const void* w_packed, void* dx, int dtype, int n, int h, int w, int c_in,
+                          int c_out, sfvos_stream_t stream);
+/* Weight gradient: grad_w[ci][co][a][b] (fp32, state-dict layout) (=|+=) sum_{n,i,j} x[n][i][j][ci] dz[n][2i+a][2j+b][co]
+ * (exact-f32 MFMA, fixed-order split reduction); workspace: sfvos_deconv2x2_wgrad_workspace_bytes. */
+size_t sfvos_deconv2x2_wgrad_workspace_bytes(int n, int h, int w, int c_in, int c_out);
+int sfvos_deconv2x2_wgrad(const void* x, const void* dz, int dtype, int n, int h, int w, int c_in, int c_out,
+                          float* grad_w, int accumulate, void* workspace, sfvos_stream_t stream);
+
 /* ---- evaluation-side reducer (reference code/helpers/davis_evaluate.py:40-42) ------------ */
 
 /* out[i] = OR over the n predicted masks of (masks[k][i] >= threshold), i < hw: the per-frame union the reference

@@ -7,6 +7,7 @@ torch-core ops:
   * models/detection/mask_rcnn.py  MaskRCNNHeads     4 x [Conv2d(256,256,3,1,1) + ReLU], kaiming_normal_(fan_out, relu)
   * models/detection/mask_rcnn.py  MaskRCNNPredictor  ConvTranspose2d(256,256,2,2,0) + ReLU + Conv2d(256,K,1,1,0)
   * models/detection/roi_heads.py  maskrcnn_inference sigmoid, pick the label's channel
+  * models/detection/roi_heads.py  maskrcnn_loss      BCE with logits on the label's channel (training, model.py:369)
   * models/detection/roi_heads.py  expand_masks / expand_boxes / paste_mask_in_image / paste_masks_in_image
 """
 from collections import OrderedDict
@@ -49,6 +50,15 @@ class OracleMaskBranch(nn.Module):
 
     def forward(self, x):
         return self.mask_predictor(self.mask_head(x))
+
+
+def maskrcnn_loss(mask_logits, labels, mask_targets):
+    """roi_heads.maskrcnn_loss behind project_masks_on_boxes (the RoIAlign of the ground-truth masks, torchvision's):
+    BCE with logits between the label's channel and the [N,M,M] targets; `sum * 0` without positive RoIs."""
+    if mask_targets.numel() == 0:
+        return mask_logits.sum() * 0
+    index = torch.arange(labels.shape[0], device=labels.device)
+    return F.binary_cross_entropy_with_logits(mask_logits[index, labels], mask_targets)
 
 
 def maskrcnn_inference(x, labels):
