@@ -196,11 +196,16 @@ class SlowFastLayers(nn.Module):
         self._fp8_sat = None          # device int: input elements that saturated in e4m3 since the last check
         self._packs = {}     # (conv name, kind, dtype) -> ((param version, data_ptr, epoch), packed tensor)
         self._timer = None
+        self._timer_only = None
         self._side = None
         self.n_streams = int(os.environ.get('SFVOS_STREAMS', '2'))
 
-    def enable_kernel_timer(self):
+    def enable_kernel_timer(self, only=None):
+        """HIP-event timing of the launches; `only`: an iterable of region names ('conv_fwd/f1', ...) -- every other
+        launch goes out without event records (an event record between two kernels costs about a microsecond of
+        GPU time, ~100 of them per step)."""
         self._timer = KernelTimer()
+        self._timer_only = None if only is None else frozenset(only)
         return self._timer
 
     # ------------------------------------------------------------------ e4m3 activation scale (precision='fp8')
@@ -237,7 +242,10 @@ class SlowFastLayers(nn.Module):
     def _t(self, kind, layer):
         if self._timer is None:
             return _NULL
-        return self._timer.region('%s/%s' % (kind, layer))
+        name = '%s/%s' % (kind, layer)
+        if self._timer_only is not None and name not in self._timer_only:
+            return _NULL
+        return self._timer.region(name)
 
     # ------------------------------------------------------------------ helpers
     def _check_ready(self, ref):

@@ -6,9 +6,10 @@ print('clips/s %.2f  ms/step %.2f  whole-step TF/s %.1f' % (d['value'], d['ms_pe
 print('roofline', d['roofline'])
 k = d['kernels_ms']
 groups = {}
+steps = (d.get('kernel_events') or {}).get('layer_table_steps') or d['steps']
 for n, (c, t) in k.items():
     g = n.split('/')[0]
-    groups[g] = groups.get(g, 0.0) + c * t / d['steps']
+    groups[g] = groups.get(g, 0.0) + c * t / steps
 print('per-step ms by kind (top-24 only):', {g: round(v, 2) for g, v in groups.items()})
 for n, (c, t) in list(k.items())[:int(sys.argv[1]) if len(sys.argv) > 1 else 14]:
     print('%-28s %8.3f' % (n, t))
