@@ -43,6 +43,26 @@ class MseTable(C.Structure):
                 ('numel', i64 * MAX_LEVELS)]
 
 
+class BnRunning(C.Structure):
+    """Mirror of sfvos_bn_running."""
+    _fields_ = [('running_mean', vp), ('running_var', vp), ('means', vp), ('vars_unbiased', vp),
+                ('num_batches_tracked', vp), ('n_updates', i32), ('momentum', f32)]
+
+
+class PackItem(C.Structure):
+    """Mirror of sfvos_pack_item."""
+    _fields_ = [('w', vp), ('packed', vp), ('c_out', i32), ('c_in', i32), ('kt', i32), ('taps', i32), ('dgrad', i32)]
+
+
+MAX_PACK_ITEMS = 16
+
+
+class PlanarLevel(C.Structure):
+    """Mirror of sfvos_planar_level."""
+    _fields_ = [('ptr', vp), ('stride_t', i64), ('stride_c', i64), ('stride_h', i64), ('stride_w', i64), ('h', i32),
+                ('w', i32)]
+
+
 def make_pyramid(shapes):
     """shapes: list of (H, W) per level."""
     if not 1 <= len(shapes) <= MAX_LEVELS:
@@ -62,7 +82,7 @@ def make_levels(shapes, batch, frames):
     return lv
 
 
-PD, PL, PM = C.POINTER(ConvDesc), C.POINTER(Levels), C.POINTER(MseTable)
+PD, PL, PM, PR = C.POINTER(ConvDesc), C.POINTER(Levels), C.POINTER(MseTable), C.POINTER(BnRunning)
 
 # name -> (restype, argtypes); every symbol include/sfvos.h declares
 SIGNATURES = {
@@ -78,9 +98,12 @@ SIGNATURES = {
     'sfvos_ndhwc_to_planar': (i32, [vp, i32, vp, i64, i32, i32, vp]),
     'sfvos_planar_to_ndhwc': (i32, [vp, vp, i32, i64, i32, i32, vp]),
     'sfvos_ndhwc_to_frames': (i32, [vp, i32, vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, i32, vp]),
+    'sfvos_pyramid_to_frames': (i32, [vp, i32, C.POINTER(PlanarLevel), i32, i32, i32, i32, i32, vp]),
+    'sfvos_frames_to_pyramid': (i32, [C.POINTER(PlanarLevel), i32, vp, i32, i32, i32, i32, vp]),
     'sfvos_packed_weight_bytes': (C.c_size_t, [i32, i32, i32, i32, i32]),
     'sfvos_pack_weights_fwd': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     'sfvos_pack_weights_dgrad': (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    'sfvos_pack_weights_batch': (i32, [C.POINTER(PackItem), i32, i32, vp]),
     'sfvos_conv3d_stat_rows': (i32, [PD, C.POINTER(i32)]),
     'sfvos_conv3d': (i32, [PD, vp, vp, vp, vp, vp, vp]),
     'sfvos_conv3d_wgrad_workspace_bytes': (C.c_size_t, [PD]),
@@ -88,8 +111,8 @@ SIGNATURES = {
     'sfvos_bn_finalize': (i32, [vp, i32, C.POINTER(i32), C.POINTER(i64), vp, vp, f32, i32, vp, vp, vp, vp, vp, i32, vp]),
     'sfvos_bn_eval_coeffs': (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp, vp, vp]),
     'sfvos_bn_running_update': (i32, [vp, vp, vp, vp, i32, i32, i32, f32, vp, vp]),
-    'sfvos_bn_apply': (i32, [vp, i32, vp, i32, i32, PL, i32, vp, vp, i32, i32, vp]),
-    'sfvos_bn_apply_fp8': (i32, [vp, i32, vp, i32, PL, i32, vp, vp, i32, i32, f32, vp, vp]),
+    'sfvos_bn_apply': (i32, [vp, i32, vp, i32, i32, PL, i32, vp, vp, i32, i32, PR, vp]),
+    'sfvos_bn_apply_fp8': (i32, [vp, i32, vp, i32, PL, i32, vp, vp, i32, i32, f32, vp, PR, vp]),
     'sfvos_bn_bwd_rows': (i32, [PL]),
     'sfvos_bn_bwd_reduce': (i32, [vp, i32, vp, i32, i32, PL, i32, vp, vp, vp, vp, i32, i32, vp, vp]),
     'sfvos_bn_bwd_finalize': (i32, [vp, PL, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
@@ -136,11 +159,12 @@ def load():
         fn.restype = res
         fn.argtypes = args
     # the binder's struct mirrors must have the library's sizes (a short struct would be read past its end)
-    sizes = (i32 * 4)()
-    n = lib.sfvos_abi_sizes(sizes, 4)
-    mine = [C.sizeof(ConvDesc), C.sizeof(Pyramid), C.sizeof(Levels), C.sizeof(MseTable)]
-    if lib.sfvos_version() < 200 or n != 4 or list(sizes) != mine:
-        raise RuntimeError('sfvos_amd: %s is ABI revision %d with struct sizes %s, this binding expects revision >= 200 '
+    sizes = (i32 * 7)()
+    n = lib.sfvos_abi_sizes(sizes, 7)
+    mine = [C.sizeof(ConvDesc), C.sizeof(Pyramid), C.sizeof(Levels), C.sizeof(MseTable), C.sizeof(BnRunning),
+            C.sizeof(PackItem), C.sizeof(PlanarLevel)]
+    if lib.sfvos_version() < 201 or n != 7 or list(sizes) != mine:
+        raise RuntimeError('sfvos_amd: %s is ABI revision %d with struct sizes %s, this binding expects revision >= 201 '
                            'and %s -- rebuild with `python __graft_entry__.py`' % (LIB_PATH, lib.sfvos_version(),
                                                                                    list(sizes)[:n], mine))
     _lib = lib

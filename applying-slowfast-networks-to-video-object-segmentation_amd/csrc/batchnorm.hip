@@ -105,11 +105,42 @@ __global__ void bn_running_update_kernel(float* rm, float* rv, const float* mean
   }
 }
 
+// the running-statistics update of bn_running_update_kernel as a prologue of the first workgroup of a BN-apply launch
+struct RunUpd {
+  float* rm; float* rv; const float* means; const float* vars; long long* nbt; int n; float momentum;
+};
+
+__device__ __forceinline__ void running_update_block0(const RunUpd& ru, int C, int cs) {
+  if (blockIdx.x != 0 || ru.rm == nullptr) return;
+  if (threadIdx.x == 0 && ru.nbt) *ru.nbt += ru.n;  // one forward per level (model.py:156-159)
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float m = ru.rm[c], v = ru.rv[c];
+    for (int i = 0; i < ru.n; ++i) {
+      m = (1.f - ru.momentum) * m + ru.momentum * ru.means[(long long)i * cs + c];
+      v = (1.f - ru.momentum) * v + ru.momentum * ru.vars[(long long)i * cs + c];
+    }
+    ru.rm[c] = m;
+    ru.rv[c] = v;
+  }
+}
+
+static int make_run_upd(const sfvos_bn_running* r, RunUpd* ru, const char* what) {
+  ru->rm = nullptr; ru->rv = nullptr; ru->means = nullptr; ru->vars = nullptr; ru->nbt = nullptr; ru->n = 0;
+  ru->momentum = 0.f;
+  if (r == nullptr) return SFVOS_OK;
+  SFVOS_REQUIRE(r->running_mean && r->running_var && r->means && r->vars_unbiased && r->n_updates >= 0,
+                "%s: bad sfvos_bn_running", what);
+  ru->rm = r->running_mean; ru->rv = r->running_var; ru->means = r->means; ru->vars = r->vars_unbiased;
+  ru->nbt = (long long*)r->num_batches_tracked; ru->n = r->n_updates; ru->momentum = r->momentum;
+  return SFVOS_OK;
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const char* __restrict__ x, int ld_x, char* y, int ld_y,
                                                        LevelTab lt, int C, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, int cs, int relu) {
+                                                       const float* __restrict__ shift, int cs, int relu, RunUpd ru) {
   constexpr int CE = Elt<DT>::CE, ES = 16 / CE;
+  running_update_block0(ru, C, cs);
   const int cpr = C / CE;
   const long long total = lt.mb[SFVOS_MAX_LEVELS] * cpr;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -132,7 +163,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const char* __restrict__ 
 __global__ __launch_bounds__(256) void bn_apply_fp8_kernel(const char* __restrict__ x, int ld_x, char* y, int ld_y,
                                                            LevelTab lt, int C, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, int cs, int relu,
-                                                           float act_scale, int* sat_count) {
+                                                           float act_scale, int* sat_count, RunUpd ru) {
+  running_update_block0(ru, C, cs);
   const int cpr = C / 16;
   const long long total = lt.mb[SFVOS_MAX_LEVELS] * cpr;
   int sat = 0;
@@ -355,11 +387,14 @@ extern "C" int sfvos_bn_running_update(float* rm, float* rv, const float* means,
 
 extern "C" int sfvos_bn_apply(const void* x, int ld_x, void* y, int ld_y, int dtype, const sfvos_levels* lv, int C,
                               const float* scale, const float* shift, int coef_stride, int relu,
-                              sfvos_stream_t stream) {
+                              const sfvos_bn_running* running, sfvos_stream_t stream) {
   int rc = check_act("bn_apply", dtype, C, ld_x, ld_y);
   if (rc) return rc;
   LevelTab lt;
   rc = make_level_tab(lv, &lt, "bn_apply");
+  if (rc) return rc;
+  RunUpd ru;
+  rc = make_run_upd(running, &ru, "bn_apply");
   if (rc) return rc;
   SFVOS_REQUIRE(x && y && scale && shift && coef_stride >= C, "bn_apply: bad pointer / coef_stride");
   const int ce = dtype == SFVOS_BF16 ? 8 : 4;
@@ -367,17 +402,20 @@ extern "C" int sfvos_bn_apply(const void* x, int ld_x, void* y, int ld_y, int dt
   hipStream_t s = (hipStream_t)stream;
   DT_DISPATCH(dtype,
               hipLaunchKernelGGL(bn_apply_kernel<SFVOS_F32>, dim3(grid), dim3(256), 0, s, (const char*)x, ld_x,
-                                 (char*)y, ld_y, lt, C, scale, shift, coef_stride, relu),
+                                 (char*)y, ld_y, lt, C, scale, shift, coef_stride, relu, ru),
               hipLaunchKernelGGL(bn_apply_kernel<SFVOS_BF16>, dim3(grid), dim3(256), 0, s, (const char*)x, ld_x,
-                                 (char*)y, ld_y, lt, C, scale, shift, coef_stride, relu));
+                                 (char*)y, ld_y, lt, C, scale, shift, coef_stride, relu, ru));
   return check_launch("bn_apply");
 }
 
 extern "C" int sfvos_bn_apply_fp8(const void* x, int ld_x, void* y, int ld_y, const sfvos_levels* lv, int C,
                                   const float* scale, const float* shift, int coef_stride, int relu, float act_scale,
-                                  int* sat_count, sfvos_stream_t stream) {
+                                  int* sat_count, const sfvos_bn_running* running, sfvos_stream_t stream) {
   LevelTab lt;
   int rc = make_level_tab(lv, &lt, "bn_apply_fp8");
+  if (rc) return rc;
+  RunUpd ru;
+  rc = make_run_upd(running, &ru, "bn_apply_fp8");
   if (rc) return rc;
   SFVOS_REQUIRE(x && y && scale && shift && coef_stride >= C && act_scale > 0.f, "bn_apply_fp8: bad argument");
   SFVOS_REQUIRE(C > 0 && C % 16 == 0 && ld_x >= C && ld_x % 8 == 0 && ld_y >= C && ld_y % 16 == 0 &&
@@ -385,7 +423,7 @@ extern "C" int sfvos_bn_apply_fp8(const void* x, int ld_x, void* y, int ld_y, co
                 "bn_apply_fp8: C must be a multiple of 16, ld_x of 8 (bf16), ld_y of 16 (bytes), y 16-byte aligned");
   const unsigned grid = grid_for(lt.mb[SFVOS_MAX_LEVELS] * (C / 16), 256 * 4);
   hipLaunchKernelGGL(bn_apply_fp8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const char*)x, ld_x, (char*)y,
-                     ld_y, lt, C, scale, shift, coef_stride, relu, act_scale, sat_count);
+                     ld_y, lt, C, scale, shift, coef_stride, relu, act_scale, sat_count, ru);
   return check_launch("bn_apply_fp8");
 }
 

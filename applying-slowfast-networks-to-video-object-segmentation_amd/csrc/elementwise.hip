@@ -15,16 +15,18 @@ struct PlanarView {
 
 // destination element (position, c) at (c / gdiv) * gstride + position * ld + c % gdiv: plain NDHWC is gdiv = C_max
 // (one group), the channel-group-major input layout is gdiv = ld = 32, gstride = positions * 32
+// (bodies take the block coordinates as arguments: the *_multi kernels below run them for every level of a pyramid in
+// one launch)
 template <int DT>
-__global__ __launch_bounds__(256) void to_ndhwc_kernel(const float* __restrict__ src, PlanarView v, char* dst, int ld,
-                                                       int gdiv, long long gstride, float qscale = 1.f,
-                                                       int* sat_count = nullptr) {
+__device__ __forceinline__ void to_ndhwc_body(const float* __restrict__ src, const PlanarView& v, char* dst, int ld,
+                                              int gdiv, long long gstride, float qscale, int* sat_count, int bx, int by,
+                                              int bz) {
   constexpr int CE = Elt<DT>::CE;
   __shared__ float tile[64][65];
   const int tid = threadIdx.x;
   const long long HW = (long long)v.H * v.W;
-  const long long p0 = (long long)blockIdx.x * 64;
-  const int c0 = blockIdx.y * 64, t = blockIdx.z;
+  const long long p0 = (long long)bx * 64;
+  const int c0 = by * 64, t = bz;
   {
     const int px = tid & 63, cy = tid >> 6;
     const long long p = p0 + px;
@@ -58,6 +60,13 @@ __global__ __launch_bounds__(256) void to_ndhwc_kernel(const float* __restrict__
     for (int o = 32; o > 0; o >>= 1) sat += __shfl_xor(sat, o);
     if ((tid & 63) == 0 && sat > 0) atomicAdd(sat_count, sat);
   }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void to_ndhwc_kernel(const float* __restrict__ src, PlanarView v, char* dst, int ld,
+                                                       int gdiv, long long gstride, float qscale = 1.f,
+                                                       int* sat_count = nullptr) {
+  to_ndhwc_body<DT>(src, v, dst, ld, gdiv, gstride, qscale, sat_count, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // max |src| over strided fp32 frames (e4m3 activation-scale calibration); non-negative floats order like their bits
@@ -182,14 +191,14 @@ __global__ __launch_bounds__(256) void mse_grad_kernel(MseTab t, const float* up
 // two channels); store: four consecutive lanes write the four 16-byte chunks of one position's 64-byte channel group,
 // i.e. a wave writes 1 KiB runs.  LDS rows of 129 floats: the store phase reads 8 positions x 4 chunks per half-wave
 // on 32 different banks.  (2.3 -> ~4.5 TB/s on the 2.8 GB fp32 -> 1.4 GB bf16 clip of the drop-in API.)
-__global__ __launch_bounds__(256) void to_ndhwc_bf16_vec_kernel(const float* __restrict__ src, PlanarView v, char* dst,
-                                                                int ld, int gdiv, long long gstride) {
+__device__ __forceinline__ void to_ndhwc_bf16_vec_body(const float* __restrict__ src, const PlanarView& v, char* dst,
+                                                       int ld, int gdiv, long long gstride, int bx, int by, int bz) {
   constexpr int TP = 128, RS = 129;
   __shared__ float tile[64 * RS];
   const int tid = threadIdx.x;
   const long long HW = (long long)v.H * v.W;
-  const long long p0 = (long long)blockIdx.x * TP;
-  const int c0 = blockIdx.y * 64, t = blockIdx.z;
+  const long long p0 = (long long)bx * TP;
+  const int c0 = by * 64, t = bz;
   f32x4 reg[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -221,6 +230,11 @@ __global__ __launch_bounds__(256) void to_ndhwc_bf16_vec_kernel(const float* __r
   }
 }
 
+__global__ __launch_bounds__(256) void to_ndhwc_bf16_vec_kernel(const float* __restrict__ src, PlanarView v, char* dst,
+                                                                int ld, int gdiv, long long gstride) {
+  to_ndhwc_bf16_vec_body(src, v, dst, ld, gdiv, gstride, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
 static bool planes_vectorizable(const float* src, const PlanarView& v) {
   const long long HW = (long long)v.H * v.W;
   return v.sw == 1 && v.sh == v.W && HW % 4 == 0 && v.st % 4 == 0 && v.sc % 4 == 0 && ((size_t)src & 15) == 0 &&
@@ -228,14 +242,14 @@ static bool planes_vectorizable(const float* src, const PlanarView& v) {
 }
 
 template <int DT>
-__global__ __launch_bounds__(256) void from_ndhwc_kernel(const char* __restrict__ src, int ld, float* dst, PlanarView v,
-                                                         int accumulate) {
+__device__ __forceinline__ void from_ndhwc_body(const char* __restrict__ src, int ld, float* dst, const PlanarView& v,
+                                                int accumulate, int bx, int by, int bz) {
   constexpr int CE = Elt<DT>::CE;
   __shared__ float tile[64][65];
   const int tid = threadIdx.x;
   const long long HW = (long long)v.H * v.W;
-  const long long p0 = (long long)blockIdx.x * 64;
-  const int c0 = blockIdx.y * 64, t = blockIdx.z;
+  const long long p0 = (long long)bx * 64;
+  const int c0 = by * 64, t = bz;
   constexpr int CPR = 64 / CE;
   for (int i = tid; i < 64 * CPR; i += 256) {
     const int px = i / CPR, ch = i - px * CPR;
@@ -260,6 +274,51 @@ __global__ __launch_bounds__(256) void from_ndhwc_kernel(const char* __restrict_
         *q = accumulate ? *q + tile[c][px] : tile[c][px];
       }
   }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void from_ndhwc_kernel(const char* __restrict__ src, int ld, float* dst, PlanarView v,
+                                                         int accumulate) {
+  from_ndhwc_body<DT>(src, ld, dst, v, accumulate, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// ---- the same passes for EVERY level of a pyramid in one launch (the module's output / output-gradient hand-over:
+// five launches of a few microseconds each become one).  blockIdx.x enumerates the pixel tiles of all levels.
+struct LevelViews {
+  int n;
+  PlanarView v[SFVOS_MAX_LEVELS];
+  float* planar[SFVOS_MAX_LEVELS];
+  long long pos[SFVOS_MAX_LEVELS];      // first position of the level in the pyramid buffer
+  int blk_begin[SFVOS_MAX_LEVELS + 1];
+};
+
+__device__ __forceinline__ int level_of_block(const LevelViews& t, int bx) {
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < SFVOS_MAX_LEVELS; ++k)
+    if (k < t.n && bx >= t.blk_begin[k]) l = k;
+  return l;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void from_ndhwc_multi_kernel(const char* __restrict__ src, int ld, LevelViews t,
+                                                               int accumulate) {
+  const int l = level_of_block(t, blockIdx.x);
+  from_ndhwc_body<DT>(src + t.pos[l] * ld * (16 / Elt<DT>::CE), ld, t.planar[l], t.v[l], accumulate,
+                      (int)blockIdx.x - t.blk_begin[l], blockIdx.y, blockIdx.z);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void to_ndhwc_multi_kernel(LevelViews t, char* dst, int ld) {
+  const int l = level_of_block(t, blockIdx.x);
+  to_ndhwc_body<DT>(t.planar[l], t.v[l], dst + t.pos[l] * ld * (16 / Elt<DT>::CE), ld, 1 << 30, 0ll, 1.f, nullptr,
+                    (int)blockIdx.x - t.blk_begin[l], blockIdx.y, blockIdx.z);
+}
+
+__global__ __launch_bounds__(256) void to_ndhwc_bf16_vec_multi_kernel(LevelViews t, char* dst, int ld) {
+  const int l = level_of_block(t, blockIdx.x);
+  to_ndhwc_bf16_vec_body(t.planar[l], t.v[l], dst + t.pos[l] * ld * 2, ld, 1 << 30, 0ll,
+                         (int)blockIdx.x - t.blk_begin[l], blockIdx.y, blockIdx.z);
 }
 
 // ---- evaluation: union of thresholded masks (davis_evaluate.py:40-42) ------------------------------
@@ -320,30 +379,58 @@ __global__ __launch_bounds__(256) void fp8_pack_weights_kernel(const float* __re
 // ---- weight packing -----------------------------------------------------------------------------
 // packed[cc][dt][tap][j][n][e]  (one 16-B chunk = CE reduction channels for one output channel n;
 // a conv stage (cc, dt, tap group) is one contiguous block)
+template <int DT>
+__device__ __forceinline__ void pack_one(const float* __restrict__ w, char* packed, int c_out, int c_in, int kt, int taps,
+                                         bool dgrad, long long i) {
+  typedef typename Elt<DT>::type T;
+  constexpr int CE = Elt<DT>::CE, CK = 4 * CE;
+  // N = output channels of the conv this image feeds (its reduction channels are the other count)
+  const int N = dgrad ? c_in : c_out;
+  long long k = i;
+  const int e = (int)(k % CE); k /= CE;
+  const int n = (int)(k % N); k /= N;
+  const int j = (int)(k % 4); k /= 4;
+  const int tap = (int)(k % taps); k /= taps;
+  const int dt = (int)(k % kt); k /= kt;
+  const int cc = (int)k;
+  const int c = cc * CK + j * CE + e;
+  float val;
+  if (dgrad)  // w[co = c][ci = n][kt-1-dt][taps-1-tap]
+    val = w[(((long long)c * c_in + n) * kt + (kt - 1 - dt)) * taps + (taps - 1 - tap)];
+  else  // w[co = n][ci = c][dt][tap]
+    val = w[(((long long)n * c_in + c) * kt + dt) * taps + tap];
+  ((T*)packed)[i] = Elt<DT>::from_f32(val);
+}
+
 template <int DT, bool DGRAD>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, char* packed, int c_out,
                                                            int c_in, int kt, int taps) {
-  typedef typename Elt<DT>::type T;
-  constexpr int CE = Elt<DT>::CE, CK = 4 * CE;
-  // N = output channels of the conv this image feeds, Kc = its reduction channels
-  const int N = DGRAD ? c_in : c_out, Kc = DGRAD ? c_out : c_in;
-  const long long total = (long long)N * Kc * kt * taps;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    long long k = i;
-    const int e = (int)(k % CE); k /= CE;
-    const int n = (int)(k % N); k /= N;
-    const int j = (int)(k % 4); k /= 4;
-    const int tap = (int)(k % taps); k /= taps;
-    const int dt = (int)(k % kt); k /= kt;
-    const int cc = (int)k;
-    const int c = cc * CK + j * CE + e;
-    float val;
-    if (DGRAD)  // w[co = c][ci = n][kt-1-dt][taps-1-tap]
-      val = w[(((long long)c * c_in + n) * kt + (kt - 1 - dt)) * taps + (taps - 1 - tap)];
-    else  // w[co = n][ci = c][dt][tap]
-      val = w[(((long long)n * c_in + c) * kt + dt) * taps + tap];
-    ((T*)packed)[i] = Elt<DT>::from_f32(val);
-  }
+  const long long total = (long long)c_out * c_in * kt * taps;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+    pack_one<DT>(w, packed, c_out, c_in, kt, taps, DGRAD, i);
+}
+
+// several images in ONE launch (all layers of a model after an optimiser step): block -> (item, 1024-element run)
+struct PackTab {
+  int n;
+  const float* w[SFVOS_MAX_PACK_ITEMS];
+  char* packed[SFVOS_MAX_PACK_ITEMS];
+  int c_out[SFVOS_MAX_PACK_ITEMS], c_in[SFVOS_MAX_PACK_ITEMS], kt[SFVOS_MAX_PACK_ITEMS], taps[SFVOS_MAX_PACK_ITEMS];
+  int dgrad[SFVOS_MAX_PACK_ITEMS];
+  int blk_begin[SFVOS_MAX_PACK_ITEMS + 1];
+};
+constexpr int PACK_RUN = 1024;
+
+template <int DT>
+__global__ __launch_bounds__(256) void pack_weights_batch_kernel(PackTab t) {
+  int it = 0;
+  for (int k = 1; k < t.n; ++k)
+    if ((int)blockIdx.x >= t.blk_begin[k]) it = k;
+  const long long total = (long long)t.c_out[it] * t.c_in[it] * t.kt[it] * t.taps[it];
+  const long long i0 = (long long)((int)blockIdx.x - t.blk_begin[it]) * PACK_RUN;
+  for (int u = threadIdx.x; u < PACK_RUN; u += 256)
+    if (i0 + u < total)
+      pack_one<DT>(t.w[it], t.packed[it], t.c_out[it], t.c_in[it], t.kt[it], t.taps[it], t.dgrad[it] != 0, i0 + u);
 }
 
 __global__ __launch_bounds__(32 * RL) void reduce_rows_kernel(const float* part, int rows, int C, float* out,
@@ -525,6 +612,73 @@ extern "C" int sfvos_ndhwc_to_frames(const void* src, int dtype, float* dst, int
   return check_launch("ndhwc_to_frames");
 }
 
+static int make_level_views(const sfvos_planar_level* levels, int n_levels, int T, int C, int tile_px, LevelViews* t,
+                            bool* vec, const char* what) {
+  SFVOS_REQUIRE(levels && n_levels >= 1 && n_levels <= SFVOS_MAX_LEVELS && T > 0 && C > 0, "%s: bad argument", what);
+  t->n = n_levels;
+  long long pos = 0, blk = 0;
+  *vec = true;
+  for (int l = 0; l < SFVOS_MAX_LEVELS; ++l) {
+    t->pos[l] = pos;
+    if (l < n_levels) {
+      const sfvos_planar_level& lv = levels[l];
+      SFVOS_REQUIRE(lv.ptr && lv.h > 0 && lv.w > 0, "%s: level %d: bad view", what, l);
+      t->v[l] = PlanarView{lv.stride_t, lv.stride_c, lv.stride_h, lv.stride_w, T, C, lv.h, lv.w};
+      t->planar[l] = lv.ptr;
+      *vec = *vec && planes_vectorizable(lv.ptr, t->v[l]);
+      pos += (long long)T * lv.h * lv.w;
+    } else {
+      t->v[l] = PlanarView{0, 0, 0, 0, T, C, 1, 1};
+      t->planar[l] = nullptr;
+    }
+  }
+  // first pixel tile (of tile_px positions) of each level
+  for (int l = 0; l < SFVOS_MAX_LEVELS; ++l) {
+    t->blk_begin[l] = (int)blk;
+    if (l < n_levels) blk += ceil_div64((long long)levels[l].h * levels[l].w, tile_px);
+  }
+  t->blk_begin[SFVOS_MAX_LEVELS] = (int)blk;
+  SFVOS_REQUIRE(blk < (1ll << 31), "%s: grid out of range", what);
+  return SFVOS_OK;
+}
+
+extern "C" int sfvos_pyramid_to_frames(const void* src, int dtype, const sfvos_planar_level* levels, int n_levels, int T,
+                                       int C, int ld, int accumulate, sfvos_stream_t stream) {
+  SFVOS_REQUIRE(src && ld >= C && C % 8 == 0 && ld % 8 == 0, "pyramid_to_frames: C and ld must be multiples of 8, ld >= C");
+  LevelViews t;
+  bool vec;
+  int rc = make_level_views(levels, n_levels, T, C, 64, &t, &vec, "pyramid_to_frames");
+  if (rc) return rc;
+  dim3 grid((unsigned)t.blk_begin[SFVOS_MAX_LEVELS], (unsigned)ceil_div(C, 64), (unsigned)T);
+  hipStream_t s = (hipStream_t)stream;
+  DT_DISPATCH(dtype,
+              hipLaunchKernelGGL(from_ndhwc_multi_kernel<SFVOS_F32>, grid, dim3(256), 0, s, (const char*)src, ld, t, accumulate),
+              hipLaunchKernelGGL(from_ndhwc_multi_kernel<SFVOS_BF16>, grid, dim3(256), 0, s, (const char*)src, ld, t, accumulate));
+  return check_launch("pyramid_to_frames");
+}
+
+extern "C" int sfvos_frames_to_pyramid(const sfvos_planar_level* levels, int n_levels, void* dst, int dtype, int T, int C,
+                                       int ld, sfvos_stream_t stream) {
+  SFVOS_REQUIRE(dst && ld >= C && C % 8 == 0 && ld % 8 == 0, "frames_to_pyramid: C and ld must be multiples of 8, ld >= C");
+  LevelViews t;
+  bool vec;
+  int rc = make_level_views(levels, n_levels, T, C, 128, &t, &vec, "frames_to_pyramid");
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == SFVOS_BF16 && vec && ((size_t)dst & 15) == 0) {
+    dim3 gridv((unsigned)t.blk_begin[SFVOS_MAX_LEVELS], (unsigned)ceil_div(C, 64), (unsigned)T);
+    hipLaunchKernelGGL(to_ndhwc_bf16_vec_multi_kernel, gridv, dim3(256), 0, s, t, (char*)dst, ld);
+    return check_launch("frames_to_pyramid");
+  }
+  rc = make_level_views(levels, n_levels, T, C, 64, &t, &vec, "frames_to_pyramid");
+  if (rc) return rc;
+  dim3 grid((unsigned)t.blk_begin[SFVOS_MAX_LEVELS], (unsigned)ceil_div(C, 64), (unsigned)T);
+  DT_DISPATCH(dtype,
+              hipLaunchKernelGGL(to_ndhwc_multi_kernel<SFVOS_F32>, grid, dim3(256), 0, s, t, (char*)dst, ld),
+              hipLaunchKernelGGL(to_ndhwc_multi_kernel<SFVOS_BF16>, grid, dim3(256), 0, s, t, (char*)dst, ld));
+  return check_launch("frames_to_pyramid");
+}
+
 extern "C" int sfvos_ndhwc_to_planar(const void* src, int dtype, float* dst, int64_t M, int C, int ld,
                                      sfvos_stream_t stream) {
   SFVOS_REQUIRE(M > 0 && M < (1ll << 31), "ndhwc_to_planar: bad M");
@@ -565,6 +719,36 @@ extern "C" int sfvos_pack_weights_fwd(const float* w, void* packed, int dtype, i
 extern "C" int sfvos_pack_weights_dgrad(const float* w, void* packed, int dtype, int c_out, int c_in, int kt, int taps,
                                         sfvos_stream_t stream) {
   return pack_common(w, packed, dtype, c_out, c_in, kt, taps, true, stream);
+}
+
+extern "C" int sfvos_pack_weights_batch(const sfvos_pack_item* items, int n, int dtype, sfvos_stream_t stream) {
+  SFVOS_REQUIRE(items && n >= 1 && n <= SFVOS_MAX_PACK_ITEMS, "pack_weights_batch: 1..%d items", SFVOS_MAX_PACK_ITEMS);
+  PackTab t;
+  t.n = n;
+  long long blk = 0;
+  for (int i = 0; i < SFVOS_MAX_PACK_ITEMS; ++i) {
+    t.blk_begin[i] = (int)blk;
+    if (i < n) {
+      const sfvos_pack_item& it = items[i];
+      SFVOS_REQUIRE(it.w && it.packed, "pack_weights_batch: item %d: null pointer", i);
+      SFVOS_REQUIRE(it.c_out % 32 == 0 && it.c_in % 32 == 0 && it.c_out > 0 && it.c_in > 0 && it.kt >= 1 &&
+                        (it.taps == 9 || it.taps == 1),
+                    "pack_weights_batch: item %d: unsupported shape (c_out %d c_in %d kt %d taps %d)", i, it.c_out,
+                    it.c_in, it.kt, it.taps);
+      t.w[i] = it.w; t.packed[i] = (char*)it.packed; t.c_out[i] = it.c_out; t.c_in[i] = it.c_in; t.kt[i] = it.kt;
+      t.taps[i] = it.taps; t.dgrad[i] = it.dgrad;
+      blk += ceil_div64((long long)it.c_out * it.c_in * it.kt * it.taps, PACK_RUN);
+      SFVOS_REQUIRE(blk < (1ll << 31), "pack_weights_batch: too many elements");
+    } else {
+      t.w[i] = nullptr; t.packed[i] = nullptr; t.c_out[i] = t.c_in[i] = t.kt[i] = t.taps[i] = 1; t.dgrad[i] = 0;
+    }
+  }
+  t.blk_begin[SFVOS_MAX_PACK_ITEMS] = (int)blk;
+  hipStream_t s = (hipStream_t)stream;
+  DT_DISPATCH(dtype,
+              hipLaunchKernelGGL(pack_weights_batch_kernel<SFVOS_F32>, dim3((unsigned)blk), dim3(256), 0, s, t),
+              hipLaunchKernelGGL(pack_weights_batch_kernel<SFVOS_BF16>, dim3((unsigned)blk), dim3(256), 0, s, t));
+  return check_launch("pack_weights_batch");
 }
 
 extern "C" int sfvos_mask_union(const float* masks, int n, int64_t hw, float threshold, unsigned char* out,

@@ -43,13 +43,14 @@ int device_cu_count() {
 
 }  // namespace sfvos
 
-extern "C" int sfvos_version(void) { return 200; }
+extern "C" int sfvos_version(void) { return 201; }
 
 extern "C" int sfvos_abi_sizes(int* sizes, int n) {
-  const int v[4] = {(int)sizeof(sfvos_conv_desc), (int)sizeof(sfvos_pyramid), (int)sizeof(sfvos_levels),
-                    (int)sizeof(sfvos_mse_table)};
-  for (int i = 0; i < 4 && i < n && sizes; ++i) sizes[i] = v[i];
-  return 4;
+  const int v[7] = {(int)sizeof(sfvos_conv_desc), (int)sizeof(sfvos_pyramid), (int)sizeof(sfvos_levels),
+                    (int)sizeof(sfvos_mse_table), (int)sizeof(sfvos_bn_running), (int)sizeof(sfvos_pack_item),
+                    (int)sizeof(sfvos_planar_level)};
+  for (int i = 0; i < 7 && i < n && sizes; ++i) sizes[i] = v[i];
+  return 7;
 }
 
 extern "C" const char* sfvos_last_error(void) { return sfvos::g_err; }

@@ -38,6 +38,16 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _planar_levels(tensors):
+    """sfvos_planar_level array for a list of [B,C,H,W] fp32 tensors (one per pyramid level)."""
+    arr = (_lib.PlanarLevel * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i].ptr = t.data_ptr()
+        arr[i].stride_t, arr[i].stride_c, arr[i].stride_h, arr[i].stride_w = t.stride(0), t.stride(1), t.stride(2), t.stride(3)
+        arr[i].h, arr[i].w = t.shape[2], t.shape[3]
+    return arr
+
+
 class KernelTimer(object):
     """HIP-event timing of the libsfvos launches (recorded on the stream they are launched on).
     Enabled only by bench.py / profiling; costs two event records per region."""
@@ -265,14 +275,32 @@ class SlowFastLayers(nn.Module):
         tag = (w._version, w.data_ptr(), _lib.weight_epoch())
         if hit is not None and hit[0] == tag:
             return hit[1]
-        packed = torch.empty(w.numel(), dtype=tdt, device=w.device)
-        fn = 'sfvos_pack_weights_fwd' if kind == 'fwd' else 'sfvos_pack_weights_dgrad'
-        wc = w.detach()
-        if wc.dtype != torch.float32 or not wc.is_contiguous():
-            wc = wc.float().contiguous()
-        _lib.call(fn, _ptr(wc), _ptr(packed), dt_id, layer.c_out, layer.c_in, layer.kt, layer.taps, _stream())
-        self._packs[key] = (tag, packed)
-        return packed
+        # a miss: the weights changed (optimiser step).  Every image of this kind that has been used before is stale for
+        # the same reason -- refresh them all in ONE launch (sfvos_pack_weights_batch) instead of one per layer
+        todo = [(layer, key, w, tag)]
+        for l2 in self.plan.layers:
+            k2 = (l2.conv, kind, dt_name)
+            if k2 == key or k2 not in self._packs:
+                continue
+            w2 = getattr(self, l2.conv).weight
+            t2 = (w2._version, w2.data_ptr(), _lib.weight_epoch())
+            if self._packs[k2][0] != t2 and w2.device == w.device:
+                todo.append((l2, k2, w2, t2))
+        todo = todo[:_lib.MAX_PACK_ITEMS]
+        items = (_lib.PackItem * len(todo))()
+        hold = []
+        for i, (l2, k2, w2, t2) in enumerate(todo):
+            wc = w2.detach()
+            if wc.dtype != torch.float32 or not wc.is_contiguous():
+                wc = wc.float().contiguous()
+            img = torch.empty(w2.numel(), dtype=tdt, device=w2.device)
+            hold.append(wc)
+            items[i].w, items[i].packed = wc.data_ptr(), img.data_ptr()
+            items[i].c_out, items[i].c_in, items[i].kt, items[i].taps = l2.c_out, l2.c_in, l2.kt, l2.taps
+            items[i].dgrad = 0 if kind == 'fwd' else 1
+            self._packs[k2] = (t2, img)
+        _lib.call('sfvos_pack_weights_batch', items, len(todo), dt_id, _stream())
+        return self._packs[key][1]
 
     def _packed_fp8(self, layer, act_scale):
         """(e4m3 weight image, [3][c_out] (bias, descale, weight scale) rows) of a 3x3 layer whose input was quantised
@@ -428,6 +456,7 @@ class SlowFastLayers(nn.Module):
                         stream.wait_event(ev['f1'])
                     if l.name == 'l2' and 'f2' in ev:
                         stream.wait_event(ev['f2'])
+                run = None   # running-statistics update of this layer (training), folded into its BN-apply launch
                 if train:
                     with self._t('conv_fwd', l.name):
                         _lib.call('sfvos_conv3d', ctypes.byref(d), _ptr(src), _ptr(wp), bias, _ptr(raw),
@@ -437,12 +466,15 @@ class SlowFastLayers(nn.Module):
                               _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), _ptr(cf[0, _VARU]), cs, st)
                     if bn.track_running_stats and bn.running_mean is not None:
                         # the reference runs the levels one after another: L consecutive momentum updates
-                        # (num_batches_tracked += L in the same launch)
+                        # (num_batches_tracked += L), done by the first workgroup of the BN-apply launch below
                         if bn.momentum is None:
                             raise RuntimeError('BatchNorm momentum=None (cumulative average) is not supported')
-                        _lib.call('sfvos_bn_running_update', _ptr(bn.running_mean), _ptr(bn.running_var),
-                                  _ptr(cf[0, _MEAN]), _ptr(cf[0, _VARU]), L, cs, l.c_out, float(bn.momentum),
-                                  _ptr(bn.num_batches_tracked), st)
+                        run = _lib.BnRunning()
+                        run.running_mean, run.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                        run.means, run.vars_unbiased = cf[0, _MEAN].data_ptr(), cf[0, _VARU].data_ptr()
+                        run.num_batches_tracked = bn.num_batches_tracked.data_ptr()
+                        run.n_updates, run.momentum = L, float(bn.momentum)
+                        run = ctypes.byref(run)
                 else:
                     with self._t('conv_fwd', l.name):
                         _lib.call('sfvos_conv3d', ctypes.byref(d), _ptr(src), _ptr(wp), bias, _ptr(raw), None, st)
@@ -455,11 +487,11 @@ class SlowFastLayers(nn.Module):
                     if l.dst in fp8_bufs:
                         _lib.call('sfvos_bn_apply_fp8', _ptr(raw), l.c_out, _ptr(dst, l.dst_off), dst.shape[-1],
                                   ctypes.byref(lv), l.c_out, _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), cs,
-                                  1 if l.relu else 0, float(self.fp8_act_scale), _ptr(self._fp8_sat), st)
+                                  1 if l.relu else 0, float(self.fp8_act_scale), _ptr(self._fp8_sat), run, st)
                     else:
                         _lib.call('sfvos_bn_apply', _ptr(raw), l.c_out, _ptr(dst, l.dst_off), dst.shape[-1], dt_id,
                                   ctypes.byref(lv), l.c_out, _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), cs,
-                                  1 if l.relu else 0, st)
+                                  1 if l.relu else 0, run, st)
                 if side is not None and l.name in ('f1', 'f2'):
                     ev[l.name] = torch.cuda.Event()
                     ev[l.name].record(stream)
@@ -469,12 +501,8 @@ class SlowFastLayers(nn.Module):
 
         # -- cat([slow224, fast32], 1).squeeze(2) (model.py:162) as the caller's NCHW fp32 tensors
         st = _stream()
-        off = 0
         out = bufs['out']
-        for (H, W), m in zip(shapes, merged):
-            _lib.call('sfvos_ndhwc_to_frames', _ptr(out, off * 256), dt_id, _ptr(m), 256 * H * W, H * W, W, 1, B, 256,
-                      H, W, 256, 0, st)
-            off += B * H * W
+        _lib.call('sfvos_pyramid_to_frames', _ptr(out), dt_id, _planar_levels(merged), len(merged), B, 256, 256, 0, st)
         if not keep:
             return merged, None
         state = _State()
@@ -504,13 +532,18 @@ class SlowFastLayers(nn.Module):
             return gb[name]
 
         galloc('out', zero=any(g is None for g in g_merged))
-        off = 0
-        for (H, W), g in zip(shapes, g_merged):
-            if g is not None:
-                g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.float().contiguous()
-                _lib.call('sfvos_frames_to_ndhwc', _ptr(g), 256 * H * W, H * W, W, 1, _ptr(gb['out'], off * 256),
-                          dt_id, B, 256, H, W, 256, _stream())
-            off += B * H * W
+        gs = [g if (g is None or (g.dtype == torch.float32 and g.is_contiguous())) else g.float().contiguous()
+              for g in g_merged]
+        if all(g is not None for g in gs):   # every level in one launch
+            _lib.call('sfvos_frames_to_pyramid', _planar_levels(gs), len(gs), _ptr(gb['out']), dt_id, B, 256, 256,
+                      _stream())
+        else:
+            off = 0
+            for (H, W), g in zip(shapes, gs):
+                if g is not None:
+                    _lib.call('sfvos_frames_to_ndhwc', _ptr(g), 256 * H * W, H * W, W, 1, _ptr(gb['out'], off * 256),
+                              dt_id, B, 256, H, W, 256, _stream())
+                off += B * H * W
 
         # -- phase 1 (current stream): decide what runs, allocate every buffer / workspace, pack dgrad images
         any_param = any(need_param.values())

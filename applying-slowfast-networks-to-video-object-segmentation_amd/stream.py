@@ -178,7 +178,7 @@ class SlowFastStream(object):
             lv = _lib.make_levels([(1, self.FS)], 1, cnt)
             _lib.call('sfvos_bn_apply', _ptr(raw, foff * self.FS * l.c_out), l.c_out, _ptr(buf, elem_off), ld,
                       self.dt_id, ctypes.byref(lv), l.c_out, _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), cs,
-                      1 if l.relu else 0, st)
+                      1 if l.relu else 0, None, st)
         self.done[name] = o_max
         return g
 

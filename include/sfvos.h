@@ -64,11 +64,13 @@ typedef struct sfvos_levels {
 } sfvos_levels;
 
 /* ABI revision: 100 = round 1; 200 = struct_size in sfvos_conv_desc, no `zeros` argument, sfvos_abi_sizes,
- * sfvos_add_inplace, sfvos_mse_loss / _grad, mask-head entry points. */
+ * sfvos_add_inplace, sfvos_mse_loss / _grad, mask-head entry points; 201 = sfvos_bn_running argument of the BN-apply
+ * calls, mask-branch training entry points, sfvos_pack_weights_batch, sfvos_pyramid_to_frames / sfvos_frames_to_pyramid. */
 int sfvos_version(void);
-/* sizes[0..n) = sizeof(sfvos_conv_desc), sizeof(sfvos_pyramid), sizeof(sfvos_levels), sizeof(sfvos_mse_table) as THIS
- * library was compiled; returns how many entries exist (4).  A binder compares them with its own mirrors of the
- * structs once at load time (a short struct would make the library read strides from whatever follows it). */
+/* sizes[0..n) = sizeof(sfvos_conv_desc), sizeof(sfvos_pyramid), sizeof(sfvos_levels), sizeof(sfvos_mse_table),
+ * sizeof(sfvos_bn_running), sizeof(sfvos_pack_item), sizeof(sfvos_planar_level) as THIS library was compiled; returns
+ * how many entries exist (7).  A binder compares them with its own mirrors of the structs once at load time (a short struct would make the
+ * library read strides from whatever follows it). */
 int sfvos_abi_sizes(int* sizes, int n);
 const char* sfvos_last_error(void);
 /* 0 when the current HIP device is a gfx950; SFVOS_E_NODEV otherwise. */
@@ -104,6 +106,20 @@ int sfvos_ndhwc_to_frames(const void* src, int dtype, float* dst, int64_t stride
                           int64_t stride_h, int64_t stride_w, int T, int C, int H, int W, int ld,
                           int accumulate, sfvos_stream_t stream);
 
+/* The two passes above for EVERY level of a pyramid in ONE launch (SlowFastLayers hands its five fused maps / takes
+ * their gradients level by level: five launches of a few microseconds become one).  Level l: planar fp32 tensor
+ * [T][C][h][w] addressed through element strides <-> the level's T*h*w positions of a level-major NDHWC pyramid buffer
+ * with pitch ld (levels in order, level l at position T * sum_{l' < l} h_l' w_l'). */
+typedef struct sfvos_planar_level {
+  float* ptr;
+  int64_t stride_t, stride_c, stride_h, stride_w;
+  int h, w;
+} sfvos_planar_level;
+int sfvos_pyramid_to_frames(const void* src, int dtype, const sfvos_planar_level* levels, int n_levels, int T, int C,
+                            int ld, int accumulate, sfvos_stream_t stream);
+int sfvos_frames_to_pyramid(const sfvos_planar_level* levels, int n_levels, void* dst, int dtype, int T, int C, int ld,
+                            sfvos_stream_t stream);
+
 /* ---- weights ------------------------------------------------------------------------- */
 
 /* Bytes of a packed weight image for a conv with these dims (same for fwd and dgrad packs). */
@@ -119,6 +135,16 @@ int sfvos_pack_weights_fwd(const float* w, void* packed, int dtype, int c_out, i
  * grad_input. */
 int sfvos_pack_weights_dgrad(const float* w, void* packed, int dtype, int c_out, int c_in, int kt, int taps,
                              sfvos_stream_t stream);
+
+/* Several images in ONE launch (every layer of the model after an optimiser step): items[i] is one
+ * sfvos_pack_weights_fwd (dgrad == 0) or sfvos_pack_weights_dgrad (dgrad != 0) call; 1 <= n <= SFVOS_MAX_PACK_ITEMS. */
+#define SFVOS_MAX_PACK_ITEMS 16
+typedef struct sfvos_pack_item {
+  const float* w;
+  void* packed;
+  int c_out, c_in, kt, taps, dgrad;
+} sfvos_pack_item;
+int sfvos_pack_weights_batch(const sfvos_pack_item* items, int n, int dtype, sfvos_stream_t stream);
 
 /* e4m3 operands (SFVOS_FP8).  Frames fp32 -> 64-channel groups of e4m3: element (t,h,w,c) = sat(src * scale) at byte
  * dst + (c/64)*group_stride + ((t*H+h)*W+w)*64 + c%64; C a multiple of 64. */
@@ -227,16 +253,31 @@ int sfvos_bn_running_update(float* running_mean, float* running_var, const float
                             int n_updates, int coef_stride, int C, float momentum, int64_t* num_batches_tracked,
                             sfvos_stream_t stream);
 
-/* y[m][0..C) = act(x[m][0..C) * scale_l + shift_l), act = ReLU when relu != 0 (model.py:114,122,...). */
+/* The running-statistics update of sfvos_bn_running_update folded into the BN-apply launch (its first workgroup does
+ * it; one launch less per layer in training): means / vars_unbiased are coefficient-table rows, level l at
+ * + l*coef_stride (the coef_stride of the apply call), n_updates consecutive rows applied in order. */
+typedef struct sfvos_bn_running {
+  float* running_mean;
+  float* running_var;
+  const float* means;
+  const float* vars_unbiased;
+  int64_t* num_batches_tracked; /* device int64 scalar += n_updates; may be NULL */
+  int n_updates;
+  float momentum;
+} sfvos_bn_running;
+
+/* y[m][0..C) = act(x[m][0..C) * scale_l + shift_l), act = ReLU when relu != 0 (model.py:114,122,...).
+ * running (may be NULL): also update the running statistics (see sfvos_bn_running). */
 int sfvos_bn_apply(const void* x, int ld_x, void* y, int ld_y, int dtype, const sfvos_levels* lv, int C,
-                   const float* scale, const float* shift, int coef_stride, int relu, sfvos_stream_t stream);
+                   const float* scale, const float* shift, int coef_stride, int relu, const sfvos_bn_running* running,
+                   sfvos_stream_t stream);
 
 /* The same with an e4m3 result (BASELINE config 5: the activation becomes the e4m3 operand of the next 3x3 conv):
  * y[m][c] = sat_e4m3(act(x*scale_l + shift_l) * act_scale); x bf16 with pitch ld_x (elements), y bytes with pitch ld_y;
  * C a multiple of 16; sat_count (device int, may be NULL) += values beyond +-448 before saturation. */
 int sfvos_bn_apply_fp8(const void* x, int ld_x, void* y, int ld_y, const sfvos_levels* lv, int C, const float* scale,
                        const float* shift, int coef_stride, int relu, float act_scale, int* sat_count,
-                       sfvos_stream_t stream);
+                       const sfvos_bn_running* running, sfvos_stream_t stream);
 
 /* Rows of partials sfvos_bn_bwd_reduce / _apply write for these levels (level-major). */
 int sfvos_bn_bwd_rows(const sfvos_levels* lv);

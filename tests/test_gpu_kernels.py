@@ -487,9 +487,22 @@ def test_batchnorm_forward_backward_per_level(lib, prec, C, relu):
     ld = C + 32
     xd = torch.cat(xs).to(TDT[prec]).cuda()
     y = torch.full((M, ld), 9.0, dtype=TDT[prec], device='cuda')
-    lib.call('sfvos_bn_apply', P(xd), C, P(y, 32), ld, dt, ctypes.byref(lv), C, P(cf[0, 2]), P(cf[0, 3]), cs, relu, S())
+    # the same running-statistics update folded into the BN-apply launch (sfvos_bn_running): bitwise the same result
+    rm2, rv2 = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    nbt2 = torch.full((), 3, dtype=torch.int64, device='cuda')
+    run = lib.BnRunning()
+    run.running_mean, run.running_var, run.means, run.vars_unbiased = (rm2.data_ptr(), rv2.data_ptr(),
+                                                                       cf[0, 0].data_ptr(), cf[0, 4].data_ptr())
+    run.num_batches_tracked, run.n_updates, run.momentum = nbt2.data_ptr(), L, 0.1
+    lib.call('sfvos_bn_apply', P(xd), C, P(y, 32), ld, dt, ctypes.byref(lv), C, P(cf[0, 2]), P(cf[0, 3]), cs, relu,
+             ctypes.byref(run), S())
+    assert torch.equal(rm2, rmd) and torch.equal(rv2, rvd) and int(nbt2) == 3 + L
     assert relmax(y[:, 32:].float().cpu(), torch.cat(ref_y)) < (1e-5 if prec == 'fp32' else 8e-3)
     assert torch.all(y[:, :32].float() == 9.0)
+    y2 = torch.full((M, ld), 9.0, dtype=TDT[prec], device='cuda')
+    lib.call('sfvos_bn_apply', P(xd), C, P(y2, 32), ld, dt, ctypes.byref(lv), C, P(cf[0, 2]), P(cf[0, 3]), cs, relu, None,
+             S())
+    assert torch.equal(y2, y) and int(nbt2) == 3 + L   # NULL: no update
     # backward
     dyd = torch.zeros((M, ld), dtype=TDT[prec], device='cuda')
     dyd[:, 32:] = torch.cat(dys).to(TDT[prec])
@@ -536,7 +549,7 @@ def test_bn_apply_fp8_feeds_an_e4m3_conv_in_ndhwc(lib):
     for c0, cn in ((0, 192), (192, 64)):
         xs_ = xd[:, c0:c0 + cn].contiguous()
         lib.call('sfvos_bn_apply_fp8', P(xs_), cn, P(y, c0), C, ctypes.byref(lv), cn, P(cfd[0, 2], c0), P(cfd[0, 3], c0),
-                 10 * C, 1, act, P(sat), S())
+                 10 * C, 1, act, P(sat), None, S())
     f8 = torch.float8_e4m3fn
     lvl = torch.cat([torch.full((m,), i) for i, m in enumerate(ms)])
     ref = torch.relu(x.float() * cf[lvl, 2] + cf[lvl, 3]) * act
@@ -569,6 +582,68 @@ def test_bn_apply_fp8_feeds_an_e4m3_conv_in_ndhwc(lib):
     refs = [F.conv3d(v, wq, None, padding=(0, 1, 1)) for v in xs5]
     for a, r in zip(from_pyr(out, B, cout, t_out, shapes), refs):
         assert relmax(a, r) < 1e-2
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('shapes', [[(12, 21), (6, 11), (3, 6)], [(8, 16), (4, 8)]])   # odd sizes / vectorisable
+def test_pyramid_layout_passes_in_one_launch(lib, prec, shapes):
+    """sfvos_pyramid_to_frames / sfvos_frames_to_pyramid: all levels in one launch, bit-identical to the per-level
+    sfvos_ndhwc_to_frames / sfvos_frames_to_ndhwc calls (and accumulate adds)."""
+    B, C, ld = 2, 64, 72
+    dt = lib.F32 if prec == 'fp32' else lib.BF16
+    g = torch.Generator().manual_seed(2)
+    planes = [torch.randn(B, C, H, W, generator=g).cuda() for (H, W) in shapes]
+    M = sum(B * H * W for H, W in shapes)
+    arr = (lib.PlanarLevel * len(shapes))()
+    for i, t in enumerate(planes):
+        arr[i].ptr = t.data_ptr()
+        arr[i].stride_t, arr[i].stride_c, arr[i].stride_h, arr[i].stride_w = t.stride()
+        arr[i].h, arr[i].w = t.shape[2], t.shape[3]
+    got = torch.full((M, ld), 5.0, dtype=TDT[prec], device='cuda')
+    ref = torch.full((M, ld), 5.0, dtype=TDT[prec], device='cuda')
+    lib.call('sfvos_frames_to_pyramid', arr, len(shapes), P(got), dt, B, C, ld, S())
+    off = 0
+    for t, (H, W) in zip(planes, shapes):
+        lib.call('sfvos_frames_to_ndhwc', P(t), t.stride(0), t.stride(1), t.stride(2), t.stride(3), P(ref, off * ld), dt,
+                 B, C, H, W, ld, S())
+        off += B * H * W
+    assert torch.equal(got, ref)
+    back = [torch.ones(B, C, H, W, device='cuda') for (H, W) in shapes]
+    for i, t in enumerate(back):
+        arr[i].ptr = t.data_ptr()
+    lib.call('sfvos_pyramid_to_frames', P(got), dt, arr, len(shapes), B, C, ld, 1, S())   # accumulate onto ones
+    off = 0
+    for t, (H, W) in zip(back, shapes):
+        want = got[off:off + B * H * W, :C].float().reshape(B, H, W, C).permute(0, 3, 1, 2) + 1.0
+        assert torch.equal(t, want)
+        off += B * H * W
+    with pytest.raises(RuntimeError):
+        lib.call('sfvos_frames_to_pyramid', arr, 0, P(got), dt, B, C, ld, S())
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_pack_weights_batch_equals_the_single_calls(lib, prec):
+    """sfvos_pack_weights_batch: every image bit-identical to its sfvos_pack_weights_fwd / _dgrad call."""
+    g = torch.Generator().manual_seed(8)
+    shapes = [(32, 256, 11, 9, 0), (192, 256, 2, 9, 0), (64, 32, 20, 1, 0), (32, 32, 12, 9, 1), (64, 32, 5, 1, 1),
+              (224, 256, 2, 9, 1)]
+    items = (lib.PackItem * len(shapes))()
+    ws, got, ref = [], [], []
+    for i, (co, ci, kt, taps, dg) in enumerate(shapes):
+        w = torch.randn(co, ci, kt, 3 if taps == 9 else 1, 3 if taps == 9 else 1, generator=g).cuda()
+        a = torch.zeros(w.numel(), dtype=TDT[prec], device='cuda')
+        b = torch.zeros(w.numel(), dtype=TDT[prec], device='cuda')
+        ws.append(w); got.append(a); ref.append(b)
+        items[i].w, items[i].packed = w.data_ptr(), a.data_ptr()
+        items[i].c_out, items[i].c_in, items[i].kt, items[i].taps, items[i].dgrad = co, ci, kt, taps, dg
+        lib.call('sfvos_pack_weights_dgrad' if dg else 'sfvos_pack_weights_fwd', P(w), P(b),
+                 lib.F32 if prec == 'fp32' else lib.BF16, co, ci, kt, taps, S())
+    lib.call('sfvos_pack_weights_batch', items, len(shapes), lib.F32 if prec == 'fp32' else lib.BF16, S())
+    torch.cuda.synchronize()
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):
+        lib.call('sfvos_pack_weights_batch', items, 0, lib.F32, S())
 
 
 def test_sgd_step_and_scale(lib):

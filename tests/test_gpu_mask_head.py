@@ -219,4 +219,4 @@ def test_maskrcnn_loss_alone_and_without_rois():
     assert float((lg.grad.cpu() / 3.0 - logits.grad).abs().max()) < 1e-8 + 1e-5 * float(logits.grad.abs().max())
     empty = torch.zeros(0, 3, 28, 28, device=DEV, requires_grad=True)
     z = maskrcnn_loss(empty, torch.zeros(0, dtype=torch.int64, device=DEV), torch.zeros(0, 28, 28, device=DEV))
-    assert float(z) == 0.0
+    assert float(z.detach()) == 0.0

@@ -105,13 +105,16 @@ def test_cabi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     lib.sfvos_version.restype = ctypes.c_int
-    assert lib.sfvos_version() >= 200
+    assert lib.sfvos_version() >= 201
     # struct mirrors: the binder's sizes must be the ones the library was compiled with (sfvos_abi_sizes); _lib.load()
     # enforces the same at import time
-    sizes = (ctypes.c_int * 4)()
-    assert lib.sfvos_abi_sizes(sizes, 4) == 4
+    sizes = (ctypes.c_int * 7)()
+    assert lib.sfvos_abi_sizes(sizes, 7) == 7
     assert list(sizes) == [ctypes.sizeof(_lib.ConvDesc), ctypes.sizeof(_lib.Pyramid), ctypes.sizeof(_lib.Levels),
-                           ctypes.sizeof(_lib.MseTable)]
+                           ctypes.sizeof(_lib.MseTable), ctypes.sizeof(_lib.BnRunning), ctypes.sizeof(_lib.PackItem),
+                           ctypes.sizeof(_lib.PlanarLevel)]
+    assert ctypes.sizeof(_lib.BnRunning) == 48 and ctypes.sizeof(_lib.PackItem) == 40
+    assert ctypes.sizeof(_lib.PlanarLevel) == 48
     assert ctypes.sizeof(_lib.Pyramid) == 68 and ctypes.sizeof(_lib.ConvDesc) == 152 and ctypes.sizeof(_lib.Levels) == 72
     assert _lib.ConvDesc().struct_size == 152
     _lib.load()
