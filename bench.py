@@ -278,6 +278,20 @@ def main():
                 if k in kern:
                     tf = fl[l.name] / kern[k][1] / 1e9
                     mfma[k] = {'ms': round(kern[k][1], 4), 'TFLOPs': round(tf, 1), 'frac': round(tf / peak, 3)}
+        # HBM-bound conv layers (laterals AI 88-137 F/B, fast_conv3 265): algorithmic bytes / event time.
+        # forward: read x, write y; weight gradient: read x and dy; data gradient: read dy, read + write dx (it
+        # accumulates onto the other consumer's gradient)
+        hbm_layers = {}
+        for l in plan.layers:
+            if l.name not in ('l1', 'l2', 'f3'):
+                continue
+            xin, yout = l.t_in * P * l.c_in * es, l.t_out * P * l.c_out * es
+            for kind, nbytes in (('conv_fwd', xin + yout), ('wgrad', xin + yout), ('conv_dgrad', yout + 2 * xin)):
+                k = '%s/%s' % (kind, l.name)
+                if k in kern:
+                    bw = nbytes / kern[k][1] / 1e6
+                    hbm_layers[k] = {'ms': round(kern[k][1], 4), 'gbytes': round(nbytes / 1e9, 4),
+                                     'achieved_GBps': round(bw, 1), 'frac': round(bw / 8000.0, 3)}
         total_flops = plan.train_flops(P)
         line = {
             'metric': 'clips/sec (T=32, 480x854) fwd+bwd', 'value': round(world * args.steps / dt, 4),
@@ -306,6 +320,7 @@ def main():
                                       'every launch bracketed (bracketing all ~100 launches costs 3 % of the step)'},
             'hbm_bound_passes': hbm,
             'mfma_layers': mfma,
+            'hbm_layers': hbm_layers,
             'kernels_ms': {k: [v[0], round(v[1], 4)] for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:28]},
         }
         if not args.no_cpu_baseline and world == 1:
