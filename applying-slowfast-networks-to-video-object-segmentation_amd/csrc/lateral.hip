@@ -39,13 +39,16 @@ struct LatArgs {
 };
 
 // KS = c_in / 32 reduction chunks, TIN = frames of dy (compile-time: the fragments are a register array)
-template <int KS, int TIN, bool ACC>
+// WL: the weight image fits the LDS budget (<= 80 KB: kt <= 20 for 64 channels) and is staged there; else (the (4,64)
+// configuration's kt = 41) the fragments stream from L2 as in round 1.
+template <int KS, int TIN, bool ACC, bool WL>
 __global__ __launch_bounds__(64 * LAT_DG_NW) void lateral_dgrad_kernel(LatArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // the weight image: [chunk][dt][j][c][16 B]
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // weight image -> LDS by LDS-DMA: wave wv copies the 1 KB pieces wv, wv + NW, ... (lane i lands at +16 i)
-  for (int q = wv; q < KS * a.kt * 2; q += LAT_DG_NW) glds16(a.wp + q * 1024 + lane * 16, smem + q * 1024);
+  if (WL)
+    for (int q = wv; q < KS * a.kt * 2; q += LAT_DG_NW) glds16(a.wp + q * 1024 + lane * 16, smem + q * 1024);
   const bool live = (int)blockIdx.x * LAT_DG_NW + wv < a.n_waves;  // idle waves redo the last tile without storing
   const int tile = live ? blockIdx.x * LAT_DG_NW + wv : a.n_waves - 1;
   int lvl = 0;
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(64 * LAT_DG_NW) void lateral_dgrad_kernel(LatArgs a
             *(const u32x4*)(a.dy + ((a.lv.xpos[lvl] + ((long long)b * a.t_in + f) * HW + px) * a.ld_dy + ks * 32 + g * 8) * 2);
       }
 
-  const char* wl = smem + (g * 32 + p16) * 16;  // lane part of a weight fragment address
+  const char* wl = (WL ? (const char*)smem : a.wp) + (g * 32 + p16) * 16;  // lane part of a weight fragment address
   // this lane's 4-channel runs of an output frame: [pixel half][channel half].  Loads of the previous contents are
   // unconditional (pixels beyond the level and frames beyond the clip clamped to the last valid one): a branch
   // around a load makes the compiler wait for every outstanding load before the next use.
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(64 * LAT_DG_NW) void lateral_dgrad_kernel(LatArgs a
         for (int mt = 0; mt < 2; ++mt) old[u][nt][mt] = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
     }
   }
-  __syncthreads();  // weight image complete
+  if (WL) __syncthreads();  // weight image complete
   for (int t0 = 0; t0 < a.t_out; t0 += LAT_DG_PF) {
 #pragma unroll
     for (int u = 0; u < LAT_DG_PF; ++u) {
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(64 * LAT_DG_NW) void lateral_dgrad_kernel(LatArgs a
           for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-              const u32x4 w = *(const u32x4*)(wl + (((ks * a.kt + dt) * 4) * 32 + mt * 16) * 16);
+              const u32x4 w = *(const u32x4*)(wl + (long long)(((ks * a.kt + dt) * 4) * 32 + mt * 16) * 16);
 #pragma unroll
               for (int nt = 0; nt < 2; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w),
@@ -387,20 +390,23 @@ int lateral_dgrad_try(const sfvos_conv_desc* d, const void* x, const void* w_pac
   a.n_waves = (int)waves;
   const dim3 grid((unsigned)ceil_div64(waves, LAT_DG_NW)), block(64 * LAT_DG_NW);
   const int ks = d->c_in / 32;
-  const int lds = ks * d->kt * 2048;  // the packed data-gradient image
-  if (lds > LAT_DG_MAX_LDS) return -1;
-#define SFVOS_LAT2(KSv, TINv, ACCv)                                                                \
-  if (ks == KSv && d->t_in == TINv && (d->accumulate != 0) == ACCv) {                              \
-    auto kern = lateral_dgrad_kernel<KSv, TINv, ACCv>;                                             \
+  const int image = ks * d->kt * 2048;  // the packed data-gradient image
+  const bool wl = image <= LAT_DG_MAX_LDS;
+  const int lds = wl ? image : 0;
+#define SFVOS_LAT3(KSv, TINv, ACCv, WLv)                                                           \
+  if (ks == KSv && d->t_in == TINv && (d->accumulate != 0) == ACCv && wl == WLv) {                 \
+    auto kern = lateral_dgrad_kernel<KSv, TINv, ACCv, WLv>;                                        \
     static LdsAttrOnce once;                                                                       \
     if (int rc = once.ensure((const void*)kern, LAT_DG_MAX_LDS, "lateral_dgrad")) return rc;       \
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                         \
     return check_launch("lateral_dgrad");                                                          \
   }
+#define SFVOS_LAT2(KSv, TINv, ACCv) SFVOS_LAT3(KSv, TINv, ACCv, true) SFVOS_LAT3(KSv, TINv, ACCv, false)
 #define SFVOS_LAT(KSv, TINv) SFVOS_LAT2(KSv, TINv, true) SFVOS_LAT2(KSv, TINv, false)
   SFVOS_LAT(2, 1) SFVOS_LAT(2, 2) SFVOS_LAT(2, 3) SFVOS_LAT(1, 1) SFVOS_LAT(1, 2) SFVOS_LAT(1, 3)
 #undef SFVOS_LAT
 #undef SFVOS_LAT2
+#undef SFVOS_LAT3
   return -1;
 }
 
