@@ -623,3 +623,74 @@ def test_fp8_inference_path_error_is_measured_and_bounded(sp, fp):
     m8.train()
     with pytest.raises(RuntimeError):
         m8.temporally_enhance_features(slow, fast)
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_c1_eight_centre_frames_trajectory_matches_the_oracle(fused):
+    """BASELINE config 1 as SURVEY.md 8d restates it: the reference's default (sp, fp) = (1, 1) (constants.py:7-8), 8
+    consecutive centre frames = 8 sequential B = 1 calls of temporally_enhance_features, backward after each, SGD
+    (lr 1e-3, momentum 0.9, wd 1e-4) after every 2nd (model.py:318-323,369-374; train.py:80): FOUR optimiser steps of
+    the module (fused optimiser with gradient sink, and torch.optim.SGD on the module's parameters) against the same
+    trajectory of the CPU oracle -- every clip's loss, and after the 8th clip the accumulated update p - p_init of every
+    parameter, every momentum buffer and every BN buffer (num_batches_tracked = 8 clips x 5 levels).
+    Bounds (fp32): losses 1e-5; updates and momentum buffers 1e-2 rel-L2 -- measured 2e-3: gradients of clips without a
+    ReLU-mask flip agree to 3e-5, a clip with a flipped element (a pre-activation within fp32 rounding of zero) moves
+    the gradients behind it by up to 4e-3 of their scale; BN running statistics 1e-5.
+    (Five levels whose smallest has 24 positions: BatchNorm over the 2 positions of a 1x2 level is ill-conditioned in
+    BOTH implementations -- its backward is pure cancellation.)"""
+    from sfvos_amd import FusedSGD, SlowFastLayers
+    dev = torch.device('cuda:0')
+    shapes = OrderedDict([('0', (24, 42)), ('1', (12, 21)), ('2', (6, 11)), ('3', (5, 8)), ('pool', (4, 6))])
+    g = torch.Generator().manual_seed(63)
+    frames = OrderedDict((k, torch.randn(8, 256, h, w, generator=g)) for k, (h, w) in shapes.items())
+    torch.manual_seed(5)
+    ref = OracleSlowFastLayers(256, torch.device('cpu'), 1, 1)
+    m = SlowFastLayers(256, dev, 1, 1, precision='fp32')
+    m.load_state_dict(ref.state_dict())
+    m = m.to(dev)
+    ref.train(); m.train()
+    p0 = {n: q.detach().clone() for n, q in ref.named_parameters()}
+    kw = dict(lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    opt_r = torch.optim.SGD(ref.parameters(), **kw)
+    opt = FusedSGD(m.parameters(), **kw).attach(m) if fused else torch.optim.SGD(m.parameters(), **kw)
+    opt.zero_grad(); opt_r.zero_grad()
+    for i in range(8):
+        win_r = OrderedDict((k, v[i:i + 1]) for k, v in frames.items())           # sp = fp = 1: the centre frame
+        win = OrderedDict((k, v[i:i + 1].to(dev)) for k, v in frames.items())
+        loss_r = proxy_loss(ref.temporally_enhance_features([win_r], [win_r]))
+        loss_r.backward()
+        loss = proxy_loss(m.temporally_enhance_features([win], [win]))
+        loss.backward()
+        lv, lr = float(loss.detach()), float(loss_r.detach())
+        assert abs(lv - lr) <= 1e-5 * abs(lr), (i, lv, lr)
+        if i % 2 == 1:                                                           # model.py:372-374
+            opt.step(); opt_r.step()
+            opt.zero_grad(); opt_r.zero_grad()
+    torch.cuda.synchronize()
+
+    def rel_l2(a, b):
+        a, b = a.double().flatten(), b.double().flatten()
+        return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+    zero_grad_bias = ('conv1.bias', 'conv2.bias', 'conv3.bias')   # conv bias in front of a train-mode BN: gradient 0
+    worst_u = worst_m = 0.0
+    ref_p = dict(ref.named_parameters())
+    sd_r, sd = opt_r.state_dict()['state'], opt.state_dict()['state']
+    for i, (name, p) in enumerate(m.named_parameters()):
+        if name.endswith(zero_grad_bias):
+            # the update is weight decay on round-off: the parameter itself stays within 1e-6 of its scale
+            a, b = p.detach().cpu().double(), ref_p[name].detach().double()
+            assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-9, name
+            continue
+        eu = rel_l2(p.detach().cpu() - p0[name], ref_p[name].detach() - p0[name])
+        em = rel_l2(sd[i]['momentum_buffer'].cpu(), sd_r[i]['momentum_buffer'])
+        worst_u, worst_m = max(worst_u, eu), max(worst_m, em)
+        assert eu < 1e-2 and em < 1e-2, (name, eu, em)
+    ref_b = dict(ref.named_buffers())
+    for name, bufr in m.named_buffers():
+        if name.endswith('num_batches_tracked'):
+            assert int(bufr) == int(ref_b[name]) == 8 * len(shapes)
+        else:
+            assert max_rel_err(bufr.cpu().numpy(), ref_b[name].numpy()) < 1e-5, name
+    print('C1 trajectory (%s): 8 clips, 4 optimiser steps: worst update rel-L2 %.2e, worst momentum buffer %.2e'
+          % ('FusedSGD + sink' if fused else 'torch.optim.SGD', worst_u, worst_m))
