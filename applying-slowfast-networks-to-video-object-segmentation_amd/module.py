@@ -209,6 +209,7 @@ class SlowFastLayers(nn.Module):
         self._timer_only = None
         self._side = None
         self.n_streams = int(os.environ.get('SFVOS_STREAMS', '2'))
+        self.f1_alone = True   # with two streams: the side stream starts behind fast_conv1's forward launch
 
     def enable_kernel_timer(self, only=None):
         """HIP-event timing of the launches; `only`: an iterable of region names ('conv_fwd/f1', ...) -- every other
@@ -439,7 +440,13 @@ class SlowFastLayers(nn.Module):
             side.wait_stream(main)
         ev = {}
         coef = {}
-        for l in plan.layers:
+        order = list(plan.layers)
+        if side is not None and self.f1_alone:
+            # fast_conv1's forward (57 % of the forward's time, one workgroup per CU) first and ALONE: the side stream
+            # starts behind it.  Interleaving slow_conv1's workgroups with it buys nothing (both fill every CU) and the
+            # slow pathway then overlaps the short fast_conv2/3 + BN launches, whose tails it fills.
+            order.sort(key=lambda l: l.name != 'f1')
+        for l in order:
             conv, bn = getattr(self, l.conv), getattr(self, l.bn)
             w = work[l.name]
             d, lv, src, wp, cf = w['d'], w['lv'], w['src'], w['wp'], w['cf']
@@ -461,6 +468,10 @@ class SlowFastLayers(nn.Module):
                     with self._t('conv_fwd', l.name):
                         _lib.call('sfvos_conv3d', ctypes.byref(d), _ptr(src), _ptr(wp), bias, _ptr(raw),
                                   _ptr(w['part']), st)
+                    if side is not None and self.f1_alone and l.name == 'f1':
+                        e0 = torch.cuda.Event()
+                        e0.record(stream)
+                        side.wait_event(e0)
                     _lib.call('sfvos_bn_finalize', _ptr(w['part']), L, w['rows_pl'], lv.m, _ptr(bn.weight.detach()),
                               _ptr(bn.bias.detach()), float(bn.eps), l.c_out, _ptr(cf[0, _MEAN]), _ptr(cf[0, _RSTD]),
                               _ptr(cf[0, _SCALE]), _ptr(cf[0, _SHIFT]), _ptr(cf[0, _VARU]), cs, st)

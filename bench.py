@@ -13,9 +13,12 @@ random-init weights.  A step = forward + loss + backward of one clip; gradients 
 then the optimiser steps (reference model.py:369-374), with the data-parallel all-reduce in front of it.
 The loss is the stand-in of SURVEY.md 8d (sum_l mean((out_l - target_l)^2), sfvos_amd.MSEProxyLoss: two libsfvos
 launches); nothing under oracle/ is imported outside cpu_baseline().
+Streams: the timed region uses the module's default of two HIP streams per clip (slow pathway + laterals on a side
+stream, which starts BEHIND fast_conv1's forward launch: the dominant kernel runs alone, the pathways then fill each
+other's launch tails; `--streams 1` serialises everything: 4 % slower).
 HIP events: inside the timed region only the dominant kernel (fast_conv1 forward) is bracketed -> `roofline`; the
-per-layer tables (`mfma_layers`, `hbm_bound_passes`, `kernels_ms`) come from a second, untimed pass of the same step
-with every launch bracketed (`--kernel-events all` puts them back into the timed region: 3 % slower).
+per-layer tables (`mfma_layers`, `hbm_layers`, `hbm_bound_passes`, `kernels_ms`) come from a second, untimed pass of
+the same step on ONE stream with every launch bracketed (`--kernel-events all` puts them back into the timed region).
 `dropin_api_ms_per_step` times the same step through the reference's calling convention
 (temporally_enhance_features on lists of fp32 NCHW frame tensors, model.py:157-158,340), i.e. including the
 fp32-NCHW -> bf16 layout pass that a train.py caller pays on every call.
@@ -44,10 +47,13 @@ def parse():
                     help='HIP events in the timed region: around every launch / only the dominant kernel / none')
     ap.add_argument('--no-layer-table', action='store_true',
                     help='skip the per-layer pass (every launch bracketed by events) behind the timed region')
-    ap.add_argument('--streams', type=int, default=1,
-                    help='HIP streams per clip: 1 = every launch on one stream (clean per-kernel HIP-event / rocprof '
-                         'durations, the default here); 2 = slow pathway on a side stream (module default, a few %% '
-                         'more clips/s, but concurrent kernels stretch each other\'s measured duration)')
+    ap.add_argument('--overlap-f1', action='store_true',
+                    help='with --streams 2: let the side stream start alongside fast_conv1 forward (A/B)')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='HIP streams per clip in the timed region: 2 (the module\'s default) = slow pathway + laterals '
+                         'on a side stream that starts BEHIND fast_conv1\'s forward launch, so the dominant kernel still '
+                         'runs alone and its HIP-event duration is clean; 1 = every launch on one stream (the '
+                         'per-layer pass always uses 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-dropin', action='store_true', help='skip the drop-in API (fp32 NCHW frame lists) timing')
     ap.add_argument('--ndhwc-input', action='store_true', help='hand the clip over as plain pyramid NDHWC (A/B of the grouped layout)')
@@ -167,6 +173,7 @@ def main():
     model = SlowFastLayers(256, dev, args.sp, args.fp, precision=args.precision).to(dev)
     model.train()
     model.n_streams = args.streams
+    model.f1_alone = not args.overlap_f1
     opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
     bucket = GradBucket(opt.flat_grad, coalesce=not args.per_layer_allreduce)
     if not args.no_grad_sink:
@@ -214,10 +221,12 @@ def main():
     if args.kernel_events != 'all' and not args.no_layer_table:
         # per-layer table: the same step with every launch bracketed, outside the timed region
         table_steps = max(2, min(args.steps, 10)) // 2 * 2
+        model.n_streams = 1   # one stream: every kernel runs alone, its event duration is its own
         timer = model.enable_kernel_timer()
         for i in range(table_steps):
             step(i)
         kern = timer.summary()
+        model.n_streams = args.streams
     model._timer = None
 
     # ---- the same step through the reference's calling convention: lists of fp32 NCHW frames -> layout pass inside
@@ -316,8 +325,9 @@ def main():
             'kernel_events': {'timed_region': args.kernel_events,
                               'layer_table_steps': table_steps if kern is not kern_dom else None,
                               'note': 'roofline.launch_ms: HIP events around the dominant kernel inside the timed region; '
-                                      'hbm_bound_passes / mfma_layers / kernels_ms: a separate pass of the same step with '
-                                      'every launch bracketed (bracketing all ~100 launches costs 3 % of the step)'},
+                                      'hbm_bound_passes / mfma_layers / hbm_layers / kernels_ms: a separate pass of the same '
+                                      'step on ONE stream with every launch bracketed (bracketing all ~100 launches costs '
+                                      '3 % of the step; concurrent kernels would stretch each other\'s durations)'},
             'hbm_bound_passes': hbm,
             'mfma_layers': mfma,
             'hbm_layers': hbm_layers,
