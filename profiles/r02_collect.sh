@@ -6,6 +6,10 @@ P=gpurun_out/prof_r02
 rm -rf $P; mkdir -p $P
 BENCH="python3 bench.py --no-cpu-baseline --no-dropin"
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -- $BENCH --steps 10 --warmup 4 > $P/trace.log 2>&1
+# the same with ONE stream: per-kernel durations of kernels that run alone (with two streams a small kernel queued behind
+# the other stream's full-chip kernel waits for a free CU, and rocprof counts that wait as its duration)
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace1 -- $BENCH --streams 1 --steps 10 --warmup 4 > $P/trace1.log 2>&1
+f1=$(ls $P/trace1/*/*kernel_stats.csv | head -1); cp $f1 $P/kernel_stats_1stream.csv
 rocprofv3 -L > $P/counters.txt 2>&1
 grep -o "TCC_EA0_RDREQ[A-Za-z0-9_]*\|TCC_EA0_WRREQ[A-Za-z0-9_]*\|TCC_REQ[A-Za-z0-9_]*\|TCC_BUBBLE[A-Za-z0-9_]*" $P/counters.txt | sort -u > $P/tcc_names.txt
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/fetch -- $BENCH --steps 4 --warmup 2 > $P/fetch.log 2>&1
