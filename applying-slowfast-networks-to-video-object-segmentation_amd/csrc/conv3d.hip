@@ -90,7 +90,10 @@ struct ConvCfg {
   static constexpr int HALO = (TAPS == 9) ? 1 : 0;
   static constexpr int HR = TH + 2 * HALO, HC = TW + 2 * HALO;
   static constexpr int BN = WN * NT * 32;
-  static constexpr int R = TT + 1;                    // ring slots
+  // ring slots: the TT frames of a stage + the TT frames that are in flight -- one new frame per stage inside a channel
+  // chunk, and ALL TT first frames of the next chunk during the last stage of a chunk (the ring used to be refilled at
+  // every chunk boundary with all waves waiting: a memory round trip, 8 times per workgroup for c_in = 256)
+  static constexpr int R = 2 * TT;
   static constexpr int X_SLOTS = 4 * HR * HC;         // 16-B slots per ring frame
   static constexpr int X_BYTES = ((X_SLOTS + 63) / 64) * 1024;  // whole 64-slot wave-pieces (the tail is padding)
   static constexpr int W_SLOTS = TPS * 4 * BN;
@@ -144,7 +147,6 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
   const int th = tile / tiles_w, tw = tile - th * tiles_w;
   const int h0 = th * C::TH, w0 = tw * C::TW, n0 = nb * C::BN, tb0 = a.t_first + tb * TT;
 
-  const int NF = TT + a.kt - 1;  // input frames this workgroup touches: t = tb0 - pad_t + i
   const int ncc = (CIN ? CIN : a.c_in) / CK;
   const long long HWp = (long long)H * W;
   // frame 0 of this clip inside the x buffer (t_alloc frames per clip, the conv's window starts at t_offset)
@@ -329,21 +331,18 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
   // partner on every stage (stamps: it finishes its MFMAs ~30 % later and the older half then idles
   // at the barrier); one static priority raise evens them out.
   if (C::NWAVES == 8 && wv >= 4 && !SFVOS_DBG(32)) __builtin_amdgcn_s_setprio(1);
-  for (int cc = 0; cc < ncc && S > 0; ++cc) {
-    // chunk prologue: refill the ring with the first TT frames of this chunk.  All waves must have
-    // finished the previous chunk's last stage before its live slots are overwritten.
-    if (cc > 0) __syncthreads();
-    int fslot = (cc * NF + dt_lo) % C::R;  // ring slot of frame dt (the j = 0 frame of the stage)
+  int fslot = 0;  // ring slot of frame dt (the j = 0 frame of the stage); slots advance with the frames staged
+  if (S > 0) {    // first chunk: its first TT frames and the first weight slice
     for (int i = 0; i < TT; ++i) {
       Dma d; d.do_w = false;
-      prep_frame(d, cc, dt_lo + i, wrap(fslot + i));
+      prep_frame(d, 0, dt_lo + i, wrap(fslot + i));
       issue_all(d);
     }
-    if (cc == 0) {
-      Dma d; d.do_x = false;
-      prep_w(d, 0, dt_lo, 0, 0);
-      issue_all(d);
-    }
+    Dma d; d.do_x = false;
+    prep_w(d, 0, dt_lo, 0, 0);
+    issue_all(d);
+  }
+  for (int cc = 0; cc < ncc && S > 0; ++cc) {
     for (int dt = dt_lo; dt <= dt_hi; ++dt) {
       for (int tg = 0; tg < C::NTG; ++tg, ++s) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -352,6 +351,15 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
         SFVOS_STAMP_AT(0)
         Dma d; d.do_x = d.do_w = false;
         if (!SFVOS_DBG(2)) {
+          // last temporal tap of a chunk: the first TT frames of the NEXT chunk go into the TT slots behind the live
+          // ones (nothing else is copied into the ring at this tap), so they land while this tap's stages multiply
+          if (tg == 0 && dt == dt_hi && cc + 1 < ncc && !SFVOS_DBG(4)) {
+            for (int i = 0; i < TT; ++i) {
+              Dma e; e.do_w = false;
+              prep_frame(e, cc + 1, dt_lo + i, wrap(fslot + TT + i));
+              issue_all(e);
+            }
+          }
           // next frame goes into the slot freed by frame dt-1; next stage's weights into the other buffer
           if (tg == 0 && dt < dt_hi && !SFVOS_DBG(4)) prep_frame(d, cc, dt + TT, wrap(fslot + TT));
           if (s + 1 < S && !SFVOS_DBG(8)) {
@@ -367,6 +375,7 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
       }
       fslot = wrap(fslot + 1);
     }
+    fslot = wrap(fslot + TT - 1);  // the next chunk's first frame sits behind this chunk's last TT frames
   }
 
   // ---- epilogue --------------------------------------------------------------------------------------
