@@ -502,7 +502,9 @@ struct FsCfg {
 // M16 (bf16 only): the MFMAs are v_mfma_f32_16x16x32_bf16 -- one instruction consumes a pixel's whole 64-byte
 // channel group, so the two wave halves split the 32 pixel columns instead of K (no exchange at the end).  Same
 // cycles per FLOP as 32x32x16, but the chip holds a higher clock on this shape under load.
-template <int DT, int TT, int RS, int CIN, bool M16>
+// (TAG: a second kernel that instantiates the same body needs its own specialisation -- host compilation rejects a
+// second reference to one specialisation of this device-only template)
+template <int DT, int TT, int RS, int CIN, bool M16, int TAG = 0>
 __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const ConvArgs::Part& pt) {
   typedef FsCfg<DT, TT, RS> C;
   // F8 (e4m3 operands, SFVOS_FP8): v_mfma_scale_f32_32x32x64_f8f6f4 -- one instruction consumes a pixel's whole
@@ -973,6 +975,16 @@ __global__ __launch_bounds__(512, 2) void conv3d_fs_kernel(ConvArgs a) {
 #endif
 }
 
+// Launches that consist of single-frame blocks only (T_out = 1: fast_conv3's forward): the 1-frame body alone needs
+// 2 ring slots + 2 weight buffers = 80 KB and fewer registers, so TWO workgroups share a CU (4 waves per SIMD): each
+// covers the other's memory round trip per stage (a 1-frame block prefetches one frame) and 362 workgroups fit one round.
+template <int DT, int CIN = 0>
+__global__ __launch_bounds__(512, 4) void conv3d_fs1_kernel(ConvArgs a) {
+  constexpr bool M16 = DT == SFVOS_BF16;
+  const int wg = blockIdx.x;
+  fs_body<DT, 1, 4, CIN, M16, 1>(a, wg, a.part[2]);
+}
+
 // ---- host-side planning ----------------------------------------------------------------------------
 struct ConvPlan {
   int family;  // 0 narrow 1x1 (c_out <= 32), 1 mid (c_out == 64, 1x1), 2 wide, 3 frame-split (c_out <= 32, 3x3),
@@ -1107,6 +1119,14 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
     for (int l = 0; l < d->pyr.n_levels && l < SFVOS_MAX_LEVELS; ++l)
       units += (long long)d->batch * ceil_div(d->pyr.h[l] > 0 ? d->pyr.h[l] : 1, 8) * ceil_div(d->pyr.w[l] > 0 ? d->pyr.w[l] : 1, 32);
     p->family = 3; split_frames_balanced(p->t_out, units, p); p->NT = 1; p->TH = 8; p->BN = 32;
+    if (d->t_in == 1 && d->pad_t == d->kt - 1 && d->kt > 1 && d->dtype == SFVOS_BF16) {
+      // data gradient of a conv with ONE output frame (fast_conv3): every frame of dx meets exactly one temporal tap, so
+      // a multi-frame block multiplies TT taps x TT frames of which TT are real.  Single-frame blocks multiply none in
+      // vain and run two per CU (conv3d_fs1_kernel).
+      p->l_blocks[0] = p->l_blocks[1] = 0; p->l_blocks[2] = p->t_out;
+      p->l_first[0] = p->l_first[1] = p->l_first[2] = 0;
+      p->t_blocks = p->t_out;
+    }
   } else if (d->c_out <= 32) {
     p->family = 0; split_frames(p->t_out, 4, p); p->MT = 1; p->NT = 1; p->TH = 8; p->BN = 32;
   } else if (d->c_out == 64 && d->taps == 1) {
@@ -1194,6 +1214,14 @@ static int launch(const ConvArgs& a, long long grid, hipStream_t stream) {
 
 template <int DT, int CIN = 0>
 static int launch_fs(const ConvArgs& a, long long grid, hipStream_t stream) {
+  if constexpr (DT == SFVOS_BF16) if (a.part[0].wgs == 0 && a.part[1].wgs == 0) {  // single-frame blocks only
+    constexpr int LDS1 = FsCfg<DT, 1, 4>::LDS_BYTES;
+    auto kern1 = conv3d_fs1_kernel<DT, CIN>;
+    static LdsAttrOnce once1;
+    if (int rc = once1.ensure((const void*)kern1, LDS1, "conv")) return rc;
+    hipLaunchKernelGGL(kern1, dim3((unsigned)grid), dim3(512), LDS1, stream, a);
+    return check_launch("conv3d_fs1");
+  }
   constexpr int LDS = FsCfg<DT, 4, 1>::LDS_BYTES;  // the largest of the three bodies
   static_assert(LDS >= FsCfg<DT, 2, 2>::LDS_BYTES && LDS >= FsCfg<DT, 1, 4>::LDS_BYTES, "LDS of the merged launch");
   auto kern = conv3d_fs_kernel<DT, CIN>;

@@ -227,7 +227,9 @@ def test_conv3d_window_beyond_the_buffer_reads_zero_frames(lib, prec, case):
                                   (1, 7, [(9, 16), (5, 7)], 32, 64, 5, 1), (2, 12, [(6, 10), (3, 3)], 32, 64, 11, 1),
                                   (1, 20, [(7, 9)], 32, 64, 20, 1),
                                   # kt = 41 (the (4,64) configuration): the weight image exceeds the LDS budget
-                                  (1, 43, [(5, 9), (2, 2)], 32, 64, 41, 1)])
+                                  (1, 43, [(5, 9), (2, 2)], 32, 64, 41, 1),
+                                  # fast_conv3's shape (all frames -> one): single-frame blocks, one temporal tap each
+                                  (2, 12, [(9, 37), (4, 5)], 32, 32, 12, 9)])
 def test_conv3d_dgrad_and_accumulate(lib, prec, case):
     B, T, shapes, cin, cout, kt, taps = case
     g = torch.Generator().manual_seed(99)

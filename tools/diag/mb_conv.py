@@ -154,6 +154,9 @@ if which == 'wall':
     wgrad('f3 32->32 k12', 12, 32, 32, 12, 9, reps=reps)
     wgrad('l1 32->64 k20', 22, 32, 64, 20, 1, reps=reps)
     wgrad('l2 32->64 k11', 12, 32, 64, 11, 1, reps=reps)
+if which == 'f3':
+    conv('f3 32->32 k12', 12, 32, 32, 12, 9, reps=reps)
+    conv('dgrad f3 32->32 k12', 1, 32, 32, 12, 9, pad_t=11, reps=reps, acc=1)
 if which == 'f2':
     conv('f2 32->32 k11', 22, 32, 32, 11, 9, reps=reps)
 if which == 'df2':
