@@ -7,13 +7,16 @@
 // Decomposition (one workgroup = 8 waves, 2 per SIMD):
 //   output tile  = TT output frames x (TH rows x 32 px) x BN output channels, f32 accumulators
 //   K loop       = for 64-byte channel chunk cc / for temporal tap dt / for tap group tg
-//   temporal ring: the halo tiles ((TH+2) x 34 px x 64 B) of TT+1 consecutive input frames sit in
-//                  LDS.  At temporal tap dt output frame j reads ring frame dt+j, so one weight
-//                  slice W[dt][taps][cc] feeds all TT frames (weights are streamed ONCE per
-//                  workgroup) and every ring frame is re-used by 9 spatial taps x up to TT
-//                  temporal taps.  While tap dt computes, frame dt+TT is DMA'd into the free slot.
-//   staging      : global_load_lds (LDS-DMA) 16 B per lane; weights double-buffered; one barrier
-//                  per stage.  Out-of-image / out-of-clip pixels come from a zero page.
+//   temporal ring: the halo tiles ((TH+2) x 34 px x 64 B) of consecutive input frames sit in LDS
+//                  (2 TT slots in the wide kernel, TT+1 in the frame-split kernel).  At temporal
+//                  tap dt output frame j reads ring frame dt+j, so one weight slice W[dt][taps][cc]
+//                  feeds all TT frames (weights are streamed ONCE per workgroup) and every ring
+//                  frame is re-used by 9 spatial taps x up to TT temporal taps.  While tap dt
+//                  computes, frame dt+TT is DMA'd into a free slot; at the last tap of a channel
+//                  chunk the wide kernel copies the next chunk's first TT frames instead.
+//   staging      : buffer_load ... lds (LDS-DMA) 16 B per lane; weights double-buffered; one barrier
+//                  per stage.  Out-of-image / out-of-clip pixels are zero-filled by the buffer
+//                  descriptor's range check (never read).
 //   LDS images   : chunk-major [16B chunk][row][col] and [tap][chunk][n]: every ds_read_b128 of an
 //                  MFMA operand covers 32 consecutive 16-B slots per half-wave -> conflict-free.
 //   inner loop   : branch-free: per (tap, k-step) NT B-fragment + TT*MT A-fragment reads feed
