@@ -87,7 +87,11 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const char* __restrict
   if (pix >= (long long)N * P) return;
   const int n = (int)(pix / P), p = (int)(pix - (long long)n * P);
   const T* xr = (const T*)x + pix * C;
-  const int lab = labels ? (int)labels[n] : 0;
+  // a label outside [0, K) selects no channel: prob becomes NaN (torch raises an index error there; an
+  // out-of-range label must never turn into an out-of-bounds access or an uninitialised result)
+  const long long lab64 = labels ? labels[n] : 0;
+  const int lab = (lab64 >= 0 && lab64 < K) ? (int)lab64 : -1;
+  if (prob && lab < 0 && lane == 0) prob[(long long)n * P + p] = __builtin_nanf("");
   for (int k = 0; k < K; ++k) {
     if (!logits && k != lab) continue;
     float s = 0.f;
@@ -158,7 +162,9 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restric
 //   dz[m][c] = a[m][c] > 0 ? dy[m][c] : 0 (a == NULL: dz = dy);  part[block][c] = sum over the block's rows of dz
 constexpr int RB_ROWS = 64;  // rows per block
 template <int DT>
-__global__ __launch_bounds__(256) void relu_bwd_kernel(const char* __restrict__ dy, const char* __restrict__ a, char* dz,
+// (dy is not __restrict__: the mask branch calls this in place, dz == dy; every element is read before it is written
+// by the same thread)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const char* dy, const char* __restrict__ a, char* dz,
                                                        long long M, int C, float* part) {
   constexpr int CE = Elt<DT>::CE, ES = 16 / CE;
   __shared__ float red[256][8];
@@ -206,7 +212,9 @@ __global__ __launch_bounds__(1024) void mask_bce_loss_kernel(const float* __rest
   double s = 0.0;
   for (long long i = threadIdx.x; i < total; i += 1024) {
     const int n = (int)(i / P), p = (int)(i - (long long)n * P);
-    const float z = logits[((long long)n * K + (int)labels[n]) * P + p], t = targets[i];
+    const long long lab = labels[n];
+    if (lab < 0 || lab >= K) { s += (double)__builtin_nanf(""); continue; }  // invalid label: the loss is NaN, nothing is read
+    const float z = logits[((long long)n * K + (int)lab) * P + p], t = targets[i];
     s += (double)(fmaxf(z, 0.f) - z * t + log1pf(expf(-fabsf(z))));
   }
   red[threadIdx.x] = s;
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(256) void mask_bce_grad_kernel(const float* __restr
     const long long nk = i / P;
     const int k = (int)(nk % K), n = (int)(nk / K);
     float g = 0.f;
-    if (k == (int)labels[n]) {
+    if ((long long)k == labels[n]) {   // an out-of-range label matches no channel: zero gradient
       const float z = logits[i];
       g = up * (1.f / (1.f + expf(-z)) - targets[(long long)n * P + p]);
     }

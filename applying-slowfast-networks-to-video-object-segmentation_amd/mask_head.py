@@ -74,7 +74,8 @@ class MaskRCNNHeads(nn.Module):
     def _packed(self, conv, dt_id, tdt, dgrad=False):
         w = conv.weight
         key = (id(conv), dgrad)
-        tag = (w._version, w.data_ptr(), dt_id)
+        # weight_epoch: FusedSGD rewrites parameters through raw pointers (no autograd version bump), see module.py
+        tag = (w._version, w.data_ptr(), dt_id, _lib.weight_epoch())
         hit = self._packs.get(key)
         if hit is not None and hit[0] == tag:
             return hit[1]
@@ -130,7 +131,7 @@ class MaskRCNNPredictor(nn.Module):
         dt_id, tdt = _DT[self.precision]
         N, H, W, C = x_nhwc.shape
         w = self.conv5_mask.weight
-        tag = (w._version, w.data_ptr(), dt_id)
+        tag = (w._version, w.data_ptr(), dt_id, _lib.weight_epoch())
         if self._pack is None or self._pack[0] != tag:
             wc = w.detach().float().contiguous()
             packed = torch.empty(wc.numel(), dtype=tdt, device=w.device)
@@ -144,7 +145,7 @@ class MaskRCNNPredictor(nn.Module):
 
     def _packed_dgrad(self, dt_id, tdt):
         w = self.conv5_mask.weight
-        tag = (w._version, w.data_ptr(), dt_id)
+        tag = (w._version, w.data_ptr(), dt_id, _lib.weight_epoch())
         if self._pack_d is None or self._pack_d[0] != tag:
             wc = w.detach().float().contiguous()
             packed = torch.empty(wc.numel(), dtype=tdt, device=w.device)
@@ -357,7 +358,14 @@ class MaskBranch(nn.Module):
         """RoIAligned features [N,256,14,14] -> mask logits [N,num_classes,28,28] (training-side output);
         differentiable w.r.t. the features and the parameters (backward on libsfvos kernels)."""
         ps = self._ordered_params()
-        if torch.is_grad_enabled() and roi_features.shape[0] > 0 and \
+        if roi_features.shape[0] == 0:
+            # no positive proposal / no detection: torchvision's heads return an empty [0,K,2H,2W]; stay on the graph
+            K = self.mask_predictor.mask_fcn_logits.out_channels
+            out = roi_features.new_zeros((0, K, 2 * roi_features.shape[2], 2 * roi_features.shape[3]))
+            if torch.is_grad_enabled() and roi_features.requires_grad:
+                out = out + roi_features.sum() * 0
+            return out
+        if torch.is_grad_enabled() and \
                 (roi_features.requires_grad or any(p.requires_grad for p in ps)):
             _check_gpu(roi_features, 'MaskBranch')
             return _MaskBranchFn.apply(self, roi_features, *ps)

@@ -119,7 +119,9 @@ class PackedClip(object):
            (position(l,b,t,h,w) as in include/sfvos.h) -- layout 'ndhwc'; or
            [C/32, M, 32] (bf16 only) -- layout 'grouped': the channels of a position are stored as 64-byte groups,
            group-major (sfvos_conv_desc.x_group_stride).  The first convs stream the input one 64-byte channel
-           chunk at a time; in this layout every 128-byte line they touch is used whole (fewer L2 misses).
+           chunk at a time; in this layout every 128-byte line they touch is used whole (fewer L2 misses); or
+           uint8 [C/64, M, 64] -- layout 'grouped8': OCP e4m3 bytes in 64-channel groups, quantised with
+           SlowFastLayers.fp8_input_scale (SlowFastLayers.pack_fp8 builds it; precision='fp8', inference only).
     """
 
     def __init__(self, data, shapes, batch, frames, keys=None, pad=(0, 0)):
@@ -133,10 +135,11 @@ class PackedClip(object):
         if self.pad[0] < 0 or self.pad[1] < 0 or frames < 1:
             raise ValueError('PackedClip: pad must be non-negative and at least one frame stored')
         M = batch * frames * sum(h * w for h, w in self.shapes)
-        ok = (data.dim() == 2 and data.shape[0] == M) or (data.dim() == 3 and data.shape[1] == M and data.shape[2] == 32)
+        ok = (data.dim() == 2 and data.shape[0] == M) or (data.dim() == 3 and data.shape[1] == M and data.shape[2] == 32) \
+            or (data.dim() == 3 and data.shape[1] == M and data.shape[2] == 64 and data.dtype == torch.uint8)
         if not ok:
-            raise ValueError('PackedClip: data must be [%d, C] (ndhwc) or [C/32, %d, 32] (grouped), got %s'
-                             % (M, M, tuple(data.shape)))
+            raise ValueError('PackedClip: data must be [%d, C] (ndhwc), [C/32, %d, 32] (grouped) or uint8 [C/64, %d, 64] '
+                             '(e4m3 groups), got %s' % (M, M, M, tuple(data.shape)))
 
     @property
     def window(self):
@@ -145,11 +148,13 @@ class PackedClip(object):
 
     @property
     def layout(self):
-        return 'grouped' if self.data.dim() == 3 else 'ndhwc'
+        if self.data.dim() == 3:
+            return 'grouped8' if self.data.dtype == torch.uint8 else 'grouped'
+        return 'ndhwc'
 
     @property
     def channels(self):
-        return self.data.shape[0] * 32 if self.data.dim() == 3 else self.data.shape[1]
+        return self.data.shape[0] * self.data.shape[2] if self.data.dim() == 3 else self.data.shape[1]
 
     @staticmethod
     def from_levels(levels, keys=None, layout='ndhwc', pad=(0, 0)):
@@ -249,6 +254,17 @@ class SlowFastLayers(nn.Module):
         if m > 0.0:
             self.fp8_input_scale = 448.0 / (headroom * m)
         return self.fp8_input_scale
+
+    def pack_fp8(self, fast_features):
+        """Quantise a fast window into the resident e4m3 clip `enhance_packed` takes with precision='fp8': same argument
+        as temporally_enhance_features' fast_features (list over clips of dict level -> [T,C,H,W] fp32 on the GPU);
+        scale = self.fp8_input_scale (calibrate_fp8_scale), saturation counted (fp8_saturated)."""
+        keys = list(fast_features[0].keys())
+        ts = [(torch.stack([d[k] for d in fast_features]) if len(fast_features) > 1 else fast_features[0][k].unsqueeze(0))
+              .transpose(1, 2) for k in keys]
+        self._check_ready(ts[0])
+        data = self._to_pyramid_fp8(ts, ts[0].shape[2])
+        return PackedClip(data, [tuple(t.shape[3:]) for t in ts], ts[0].shape[0], ts[0].shape[2], keys)
 
     def _t(self, kind, layer):
         if self._timer is None:
@@ -800,11 +816,13 @@ class SlowFastLayers(nn.Module):
         The slow pathway reads frames [slow_offset, slow_offset+sp) of the same clip; default = the
         centre frames, as SegmentationModel._slice_features takes them (model.py:242-248,322,337)."""
         self._check_ready(clip.data)
-        if self.precision == 'fp8':
-            raise RuntimeError("precision='fp8' takes frames (temporally_enhance_features); there is no packed e4m3 "
-                               "clip format in this build")
         plan = self.plan
         _, tdt = _DT[self.precision]
+        if self.precision == 'fp8':   # the e4m3 clip of pack_fp8 (64-channel groups, quantised with fp8_input_scale)
+            tdt = torch.uint8
+            if clip.layout != 'grouped8' or clip.pad != (0, 0):
+                raise RuntimeError("precision='fp8' takes the e4m3 clip SlowFastLayers.pack_fp8 builds (layout "
+                                   "'grouped8', whole window stored), got layout %r" % clip.layout)
         if clip.window != plan.fp or clip.channels != plan.input_size or clip.data.dtype != tdt \
                 or not clip.data.is_contiguous():
             raise RuntimeError('PackedClip must stand for %d frames (stored + zero padding) x %d channels, contiguous %s'

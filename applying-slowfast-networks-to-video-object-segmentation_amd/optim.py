@@ -56,10 +56,13 @@ class FusedSGD(torch.optim.Optimizer):
         module._grad_sink = self
         self.bucket = bucket
         if bucket is not None and hasattr(bucket, 'set_buckets'):
-            # coalesced exchange: (layer 3 + laterals), (layer 2), (layer 1) -- each group is one contiguous range of
-            # the flat buffer in the reference's registration order (model.py:47-67: the laterals come last)
+            # coalesced exchange: (layer 3), (layer 2), (both laterals), (layer 1) -- each group is one contiguous
+            # range of the flat buffer in the reference's registration order (model.py:47-67: f1 s1 f2 s2 f3 s3 l1 l2)
+            # and completes in that order during backward (f3 s3 l2 f2 s2 l1 f1 s1): layer 3 goes out first and only
+            # layer 1's bucket has no backward left to overlap with (with the laterals in layer 3's bucket
+            # nothing could go out before conv_f2s1's backward)
             ranges = []
-            for group in (('f3', 's3', 'l1', 'l2'), ('f2', 's2'), ('f1', 's1')):
+            for group in (('f3', 's3'), ('f2', 's2'), ('l1', 'l2'), ('f1', 's1')):
                 spans = []
                 for name in group:
                     l = module.plan.layer(name)

@@ -5,11 +5,15 @@ The reference's SlowFast path is single-process; clips are indepe
 so they shard across ranks with ONE exchange step per optimiser step: the all-reduce(sum) of the
 flat gradient buffer (3.9 M fp32 at (sp,fp)=(4,32)), averaged by world size.  The collectives
 run on a side stream while backward is still producing the earlier layers' gradients: the flat
-buffer is cut into (at most) three contiguous buckets -- layer 3 + laterals, layer 2, layer 1 --
-and each is all-reduced the moment backward has enqueued the last kernel writing into it, so only
-the first layer's bucket cannot overlap; the optimiser waits for all of them.  xGMI is point to
-point: three collectives of 4-7 MB keep the per-call RCCL launch latency (x3, not x8) small
-against the transfer time while still hiding two of them behind backward.
+buffer is cut into (at most) four contiguous buckets -- layer 3, layer 2, both laterals, layer 1, in
+the order backward completes them (f3 s3 l2 f2 s2 l1 f1 s1; the laterals sit together at the end of
+the reference's registration order, so their range is complete once conv_f2s1's backward has run,
+behind layer 2) -- and each is all-reduced the moment backward has enqueued the last kernel writing
+into it, so only the first layer's bucket cannot overlap; the optimiser waits for all of them.
+xGMI is point to point: collectives of 0.3-7 MB keep the per-call RCCL launch latency (x4, not x8)
+small against the transfer time while still hiding three of them behind backward.  The overlap is
+verified on RCCL with ONE rank only (tests/test_gpu_rccl.py: librccl loads, the side-stream ordering
+and finish() hold on the real backend); its effect on a multi-GPU step is the driver's measurement.
 BatchNorm statistics stay per replica (the reference has no SyncBN)."""
 import os
 
@@ -17,13 +21,17 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend=None):
+def init_distributed(backend=None, force=False):
     """Initialise the default process group from the torchrun environment (RANK, WORLD_SIZE,
-    LOCAL_RANK, MASTER_ADDR, MASTER_PORT).  Returns (rank, world_size, local_rank)."""
+    LOCAL_RANK, MASTER_ADDR, MASTER_PORT).  Returns (rank, world_size, local_rank).
+    force: create the process group even for ONE rank (bench.py --force-dist, tests/test_gpu_rccl.py: the RCCL path of
+    the gradient exchange on a single GPU)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if force:
+        os.environ.setdefault('MASTER_PORT', '29543')
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:  # SFVOS_DIST_BACKEND=gloo: rehearse the multi-rank control flow without RCCL
             backend = os.environ.get('SFVOS_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -46,13 +54,17 @@ class GradBucket(object):
     ran on -- and each range is all-reduced at once on a side stream (RCCL over xGMI) while backward continues with the
     earlier layers; finish() waits for the collectives, reduces whatever was not reported, and applies 1/world."""
 
-    def __init__(self, flat_grad, group=None, coalesce=True):
+    def __init__(self, flat_grad, group=None, coalesce=True, force=False):
+        """force: run the collectives even when the group has ONE rank (an all-reduce over one rank is the identity;
+        this is how the RCCL path is exercised on a single GPU)."""
         self.flat = flat_grad
         self.group = group
         self.coalesce = coalesce   # False: every reported segment is its own collective (A/B)
         self._buckets = []         # [lo, hi) ranges all-reduced as ONE collective each once fully reported
         self._ready = []           # segments reported since arm() that have not been sent yet
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (bool(force) and dist.is_initialized())
+        self.collectives = 0       # all-reduce calls issued so far (tests / bench report)
         self._works = []
         self._stream = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
         self._armed = False
@@ -60,7 +72,7 @@ class GradBucket(object):
 
     # -- whole buffer -------------------------------------------------------------------------------------
     def start(self):
-        if self.world == 1:
+        if not self.active:
             return
         self._armed = False
         self._launch(0, self.flat.numel())
@@ -75,6 +87,7 @@ class GradBucket(object):
                 self._works.append(dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self._works.append(dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.collectives += 1
         self._sent.append((lo, hi))
 
     # -- overlapped with backward -------------------------------------------------------------------------
@@ -89,7 +102,7 @@ class GradBucket(object):
 
     def arm(self):
         """The next backward produces the gradients to exchange: accept segment_ready() calls."""
-        self._armed = self.world > 1
+        self._armed = self.active
         self._sent = []
         self._ready = []
 
@@ -130,7 +143,7 @@ class GradBucket(object):
         self._launch(bucket[0], bucket[1], streams or None)
 
     def finish(self):
-        if self.world == 1:
+        if not self.active:
             return
         # whatever has not been handed to the collective yet (nothing at all when neither start() nor arm() ran:
         # finish() alone is then a whole-buffer all-reduce -- it never scales unreduced gradients)

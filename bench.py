@@ -42,7 +42,9 @@ def parse():
     ap.add_argument('--warmup', type=int, default=4)
     ap.add_argument('--sp', type=int, default=4)
     ap.add_argument('--fp', type=int, default=32)
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32', 'fp8'],
+                    help="fp8 = BASELINE config 5: eval-mode FORWARD only (the e4m3 path has no backward), its own metric "
+                         "name so that the line cannot be mistaken for the headline")
     ap.add_argument('--kernel-events', choices=['all', 'dominant', 'none'], default='dominant',
                     help='HIP events in the timed region: around every launch / only the dominant kernel / none')
     ap.add_argument('--no-layer-table', action='store_true',
@@ -60,9 +62,12 @@ def parse():
     ap.add_argument('--no-grad-sink', action='store_true',
                     help='let autograd accumulate parameter gradients from temporaries (A/B of FusedSGD.attach)')
     ap.add_argument('--per-layer-allreduce', action='store_true',
-                    help='one all-reduce per layer instead of the 3 coalesced buckets (A/B)')
+                    help='one all-reduce per layer instead of the 4 coalesced buckets (A/B)')
     ap.add_argument('--cpu-threads', type=int, default=0)
-    ap.add_argument('--cpu-clips', type=int, default=3, help='timed clips of the CPU baseline (after 1 warm-up)')
+    ap.add_argument('--cpu-clips', type=int, default=5, help='timed clips of the CPU baseline (after 1 warm-up)')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='create the RCCL (nccl) process group even with ONE rank and send the gradient buckets through it '
+                         '(an all-reduce over one rank is the identity): the RCCL path of the exchange on a single GPU')
     ap.add_argument('--master-port', type=int, default=29541)
     return ap.parse_args()
 
@@ -137,6 +142,9 @@ def pmc_traffic(path, kernel):
         return None
 
 
+PMC_SUMMARY = 'r02_pmc_summary.json'   # the committed counter summary `roofline.traffic` is read from
+
+
 def make_step(model, opt, bucket, loss_fn, forward):
     """One bench step (also driven, at world size 2 over gloo, by tests/test_gpu_dp.py): forward + loss + backward of
     one clip; every 2nd clip completes the gradients: all-reduce (overlapped with that backward), optimiser step."""
@@ -153,6 +161,95 @@ def make_step(model, opt, bucket, loss_fn, forward):
     return step
 
 
+def main_fp8(args):
+    """BASELINE config 5: the e4m3 conv path, eval-mode FORWARD of one (sp, fp) clip over the DAVIS
+    pyramid -- fast_conv1 and slow_conv1-3 (99 % of the forward FLOPs) on v_mfma_scale_f32_32x32x64_f8f6f4 with e4m3
+    operands, f32 accumulate, bf16 results; the 32-channel layers stay bf16.  The clip is resident in HBM as e4m3
+    64-channel groups (SlowFastLayers.pack_fp8).  Not the headline metric: no backward exists in e4m3, so the line
+    carries its own metric name.  The bf16 eval forward of the same clip is timed beside it."""
+    import torch
+    from sfvos_amd import PackedClip, SlowFastLayers, davis_pyramid
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(63)
+    pyr = davis_pyramid()
+    P = sum(h * w for _, (h, w) in pyr)
+    gen = torch.Generator(device=dev).manual_seed(63)
+    model = SlowFastLayers(256, dev, args.sp, args.fp, precision='fp8').to(dev)
+    model.eval()
+    model.n_streams = args.streams
+    from collections import OrderedDict
+    fast = OrderedDict((k, torch.randn((args.fp, 256, h, w), generator=gen, device=dev)) for k, (h, w) in pyr)
+    model.calibrate_fp8_scale([fast])
+    clip8 = model.pack_fp8([fast])
+    levels = [v.permute(0, 2, 3, 1).unsqueeze(0).to(torch.bfloat16) for v in fast.values()]
+    clip16 = PackedClip.from_levels(levels, keys=[k for k, _ in pyr], layout='grouped')
+    del levels, fast
+    sat = model.fp8_saturated()
+
+    def run(precision, clip, steps, warmup, only):
+        model.precision = precision
+        timer = model.enable_kernel_timer(only)
+        with torch.no_grad():
+            for _ in range(warmup):
+                model.enhance_packed(clip)
+            timer.reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                model.enhance_packed(clip)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        k = timer.summary()
+        model._timer = None
+        return dt, k
+
+    dt, kdom = run('fp8', clip8, args.steps, args.warmup, ['conv_fwd/f1'])
+    model.n_streams = 1
+    _, k8 = run('fp8', clip8, 6, 2, None)
+    _, k16 = run('bf16', clip16, 6, 2, None)
+    model.n_streams = args.streams
+    dt16, _ = run('bf16', clip16, args.steps, args.warmup, [])
+    plan = model.plan
+    l = plan.layer('f1')
+    fl = plan.layer_flops(P)
+    dom = kdom['conv_fwd/f1']
+    ach = fl['f1'] / (dom[1] * 1e-3) / 1e12
+    layers = {}
+    for name in ('s1', 'f1', 's2', 's3'):
+        a, b = k8.get('conv_fwd/' + name), k16.get('conv_fwd/' + name)
+        if a and b:
+            layers[name] = {'fp8_ms': round(a[1], 4), 'bf16_ms': round(b[1], 4),
+                            'fp8_TFLOPs': round(fl[name] / a[1] / 1e9, 1), 'frac_of_5PF': round(fl[name] / a[1] / 1e9 / 5000.0, 3)}
+    line = {
+        'metric': 'clips/sec (T=%d, 480x854) eval FORWARD only, e4m3 conv operands (BASELINE config 5; not the headline fwd+bwd metric)' % args.fp,
+        'value': round(args.steps / dt, 3), 'unit': 'clips/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'fp8 (e4m3 operands of the four Cin=256 convs, f32 accumulate, bf16 results; 32-channel layers bf16)',
+        'data': 'synthetic',
+        'config': {'workload': 'SlowFastLayers (sp=%d, fp=%d) eval forward, 1 clip/step, 5 FPN levels of a 480x854 frame '
+                               '(P=%d); input = e4m3 clip resident in HBM ([C/64][pos][64] groups, per-tensor scale %.3g, '
+                               '%d of %d elements saturated)' % (args.sp, args.fp, P, model.fp8_input_scale, sat,
+                                                                 args.fp * P * 256),
+                   'parallelism': 'dp1', 'hip_streams_per_clip': args.streams},
+        'bf16_forward_ms_per_step': round(1e3 * dt16 / args.steps, 3),
+        'fp8_over_bf16_forward': round(dt16 / dt, 3),
+        'tflops_per_clip_forward': round(plan.forward_flops(P) / 1e12, 3),
+        'roofline': {'bound': 'mfma',
+                     'kernel': 'sfvos::conv3d_fs_kernel<2,256> (fast_conv1 forward on e4m3 operands, 256->32 ch, %dx3x3, '
+                               '%d->%d frames, one launch)' % (l.kt, l.t_in, l.t_out),
+                     'achieved': round(ach, 2), 'peak': 5000.0, 'unit': 'TFLOP/s', 'frac': round(ach / 5000.0, 4),
+                     'launch_ms': round(dom[1], 4), 'flops_per_launch': fl['f1'], 'traffic': None},
+        'fp8_layers': layers,
+        'kernels_ms': {k: [v[0], round(v[1], 4)] for k, v in sorted(k8.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:20]},
+        'cpu_baseline': None,
+        'note': 'tolerance of this path (tests/test_gpu_parity.py::test_fp8_inference_path_error_is_measured_and_bounded): '
+                'fused maps 5 % rel-L2 against the fp32 oracle, argmax agreement 92-98 %',
+    }
+    print(json.dumps(line))
+    sys.stdout.flush()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -163,7 +260,10 @@ def main():
     from sfvos_amd import (FusedSGD, GradBucket, MSEProxyLoss, PackedClip, SlowFastLayers, davis_pyramid,
                            init_distributed)
 
-    rank, world, local = init_distributed()
+    if args.precision == 'fp8':
+        return main_fp8(args)
+    rank, world, local = init_distributed(force=args.force_dist)
+    dist_on = world > 1 or args.force_dist
     if world != args.gpus and rank == 0:
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
     dev = torch.device('cuda', (local % torch.cuda.device_count()) if world > 1 else 0)
@@ -175,7 +275,7 @@ def main():
     model.n_streams = args.streams
     model.f1_alone = not args.overlap_f1
     opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
-    bucket = GradBucket(opt.flat_grad, coalesce=not args.per_layer_allreduce)
+    bucket = GradBucket(opt.flat_grad, coalesce=not args.per_layer_allreduce, force=args.force_dist)
     if not args.no_grad_sink:
         # kernels write parameter gradients straight into the flat gradient buffer; with world > 1 the finished
         # layers' slices are all-reduced (RCCL, side stream) while backward continues
@@ -267,8 +367,10 @@ def main():
                                   % ('1' if args.precision == 'bf16' else '0', l.kt, l.t_in, l.t_out),
                         'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                         'launch_ms': round(dom[1], 4), 'flops_per_launch': dom_flops,
-                        'traffic': pmc_traffic(os.path.join(ROOT, 'profiles', 'r02_pmc_summary.json'),
-                                               'conv3d_fs_kernel<1, 256>') if headline else None}
+                        'traffic': pmc_traffic(os.path.join(ROOT, 'profiles', PMC_SUMMARY),
+                                               'conv3d_fs_kernel<1, 256>') if headline else None,
+                        'traffic_source': ('profiles/%s (static: rocprofv3 --pmc passes of this command, committed; '
+                                           'not re-measured in this run)' % PMC_SUMMARY) if headline else None}
         # HBM-bound passes: algorithmic bytes (each tensor touched once per pass) / HIP-event time
         es = 2 if args.precision == 'bf16' else 4
         hbm = {}
@@ -312,9 +414,10 @@ def main():
                                    'no layout pass in the timed region)'
                                    % (args.sp, args.fp, P, ('channel-group-major [C/32][pos][32] bf16' if grouped else
                                                             'pyramid NDHWC %s' % args.precision)),
-                       'parallelism': 'dp%d' % world, 'backend': (dist.get_backend() if world > 1 else 'none'),
+                       'parallelism': 'dp%d' % world, 'backend': (dist.get_backend() if dist_on else 'none'),
+                       'allreduce_collectives_issued': bucket.collectives,
                        'grad_accumulation': 2, 'hip_streams_per_clip': args.streams,
-                       'allreduce_buckets': ('per-layer' if args.per_layer_allreduce else 3) if world > 1 else 0},
+                       'allreduce_buckets': ('per-layer' if args.per_layer_allreduce else 4) if dist_on else 0},
             'dropin_api_ms_per_step': None if dropin_ms is None else round(dropin_ms, 3),
             'dropin_api_note': 'same step through temporally_enhance_features([slow], [fast]) on fp32 NCHW frame lists '
                                '(reference calling convention, model.py:157-158,340): includes the fp32 NCHW -> '
@@ -339,7 +442,7 @@ def main():
             line['cpu_baseline'] = None
         print(json.dumps(line))
         sys.stdout.flush()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

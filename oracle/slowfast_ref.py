@@ -59,6 +59,13 @@ class OracleSlowFastLayers(nn.Module):
         # tests may set this to a list: every ReLU then appends min |input| (how far the clip is from a mask flip
         # between two correct implementations -- the ReLU derivative is discontinuous at 0)
         self.relu_margins = None
+        # tests may set relu_masks = {(level key, bn name): bool [B,C,T,H,W]}: the ReLU of that layer then uses the GIVEN
+        # mask (y * mask) instead of its own (y > 0), and relu_flips[(level key, bn name)] counts the elements whose
+        # own mask differs -- the experiment behind DESIGN.md's "ReLU-mask flips" (two correct implementations put a
+        # pre-activation within round-off of 0 on different sides).  Default None: the reference's arithmetic, untouched.
+        self.relu_masks = None
+        self.relu_flips = {}
+        self._level_key = None
         kt = {'fast_conv1': kf[0], 'slow_conv1': ks[0], 'fast_conv2': kf[1], 'slow_conv2': ks[1],
               'fast_conv3': kf[2], 'slow_conv3': ks[2]}
         for conv, bn, cin, cout in _MAIN:
@@ -80,6 +87,10 @@ class OracleSlowFastLayers(nn.Module):
                          training=self.training, momentum=0.1, eps=1e-5)
         if relu and self.relu_margins is not None:
             self.relu_margins.append(float(y.detach().abs().min()))
+        if relu and self.relu_masks is not None and (self._level_key, bn) in self.relu_masks:
+            mask = self.relu_masks[(self._level_key, bn)]
+            self.relu_flips[(self._level_key, bn)] = int(((y.detach() > 0) != mask).sum())
+            return y * mask.to(y.dtype)
         return F.relu(y) if relu else y
 
     def forward(self, slow, fast):
@@ -96,6 +107,7 @@ class OracleSlowFastLayers(nn.Module):
     def temporally_enhance_features(self, slow_features, fast_features):
         merged = OrderedDict()
         for key in slow_features[0].keys():
+            self._level_key = key
             s = torch.stack([d[key] for d in slow_features]).to(self.device).transpose(1, 2)
             f = torch.stack([d[key] for d in fast_features]).to(self.device).transpose(1, 2)
             s, f = self.forward(s, f)

@@ -1,6 +1,6 @@
 """GPU, two ranks sharing cuda:0, gloo transport (the collective library is not the thing under test; RCCL needs
 one GPU per rank): the gradient exchange SlowFastLayers' backward drives through FusedSGD.attach(module, bucket) --
-the flat gradient all-reduced in three coalesced buckets (or layer by layer) as soon as backward has produced them --
+the flat gradient all-reduced in four coalesced buckets (or layer by layer) as soon as backward has produced them --
 must leave the average of the ranks' local gradients in every rank's buffer; and bench.py's own step function, run at
 world size 2, must leave both ranks with identical parameters equal to the single-process result on the same clips."""
 import os
@@ -55,10 +55,13 @@ def _worker_body(rank, world, port, q):
             bucket.arm()
         loss.backward()
         if exchange:
-            sent = sorted(bucket._sent)
-            if coalesce:   # (f1,s1) (f2,s2) (f3,s3,l1,l2): three collectives that tile the whole buffer
-                assert len(sent) == 3 and sent[0][0] == 0 and sent[-1][1] == opt.flat_grad.numel(), sent
+            order = list(bucket._sent)
+            sent = sorted(order)
+            if coalesce:   # (f1,s1) (f2,s2) (f3,s3) (l1,l2): four collectives that tile the whole buffer ...
+                assert len(sent) == 4 and sent[0][0] == 0 and sent[-1][1] == opt.flat_grad.numel(), sent
                 assert all(a[1] == b[0] for a, b in zip(sent, sent[1:])), sent
+                # ... and go out in the order backward completes them: layer 3, layer 2, laterals, layer 1
+                assert order == [sent[2], sent[1], sent[3], sent[0]], (order, sent)
             else:
                 assert len(sent) >= 8, 'backward did not report its layers'
             bucket.finish()

@@ -220,3 +220,106 @@ def test_maskrcnn_loss_alone_and_without_rois():
     empty = torch.zeros(0, 3, 28, 28, device=DEV, requires_grad=True)
     z = maskrcnn_loss(empty, torch.zeros(0, dtype=torch.int64, device=DEV), torch.zeros(0, 28, 28, device=DEV))
     assert float(z.detach()) == 0.0
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_mask_branch_fused_sgd_trajectory_matches_the_oracle(precision):
+    """the reference trains roi_heads under the same SGD as everything else (train.py:80,
+    model.py:176-179).  FusedSGD rewrites the parameters through raw pointers, so the branch's packed weight images
+    (3x3 fwd / dgrad, deconv fwd / dgrad) must follow _lib.weight_epoch(): four optimiser steps of MaskBranch under
+    the package's FusedSGD against the oracle under torch.optim.SGD -- losses of every step (a stale image shows from
+    step 2 on), logits after the last step, and the parameters themselves.  lr is raised to 0.05 so that one step
+    moves the logits far beyond the tolerance."""
+    from sfvos_amd import FusedSGD, maskrcnn_loss
+    m, o = make(precision)
+    N = 6
+    labels = torch.tensor([1, 0, 1, 1, 0, 1])
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(N, 256, 14, 14, generator=g).relu()
+    targets = (torch.rand(N, 28, 28, generator=g) > 0.5).float()
+    if precision == 'bf16':
+        x = x.bfloat16().float()
+    opt = FusedSGD(m.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    ropt = torch.optim.SGD(o.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    xg = x.to(DEV)
+    losses, rlosses = [], []
+    for step in range(4):
+        opt.zero_grad()
+        loss = maskrcnn_loss(m(xg), labels.to(DEV), targets.to(DEV))
+        loss.backward()
+        opt.step()
+        ropt.zero_grad()
+        rl = ref_loss(o(x), labels, targets)
+        rl.backward()
+        ropt.step()
+        losses.append(float(loss.detach()))
+        rlosses.append(float(rl.detach()))
+    with torch.no_grad():
+        got, ref = m(xg).cpu(), o(x)
+    tol_l, tol_o = (2e-4, 2e-3) if precision == 'fp32' else (5e-2, 0.15)
+    print('mask branch %s FusedSGD trajectory: losses %s vs oracle %s; logits after 4 steps %.2e'
+          % (precision, ['%.5f' % v for v in losses], ['%.5f' % v for v in rlosses], relmax(got, ref)))
+    assert abs(rlosses[0] - rlosses[-1]) > 20 * tol_l * abs(rlosses[0]), 'the trajectory must move'
+    for a, b in zip(losses, rlosses):
+        assert abs(a - b) <= tol_l * abs(b), (losses, rlosses)
+    assert relmax(got, ref) < tol_o
+    names = dict(o.named_parameters())
+    for name, p in m.named_parameters():
+        a, b = p.detach().cpu().double().flatten(), names[name].detach().double().flatten()
+        assert float((a - b).norm() / b.norm()) < tol_o, name
+
+
+def test_mask_branch_without_rois_and_with_bad_labels():
+    """forward() with zero RoIs returns an empty [0,K,28,28] that stays on the graph (torchvision's
+    heads do); a label outside [0, num_classes) never becomes an out-of-bounds read -- probabilities and the loss are
+    NaN (torch raises an index error there), its gradient is zero."""
+    from sfvos_amd import maskrcnn_loss
+    m, _ = make('fp32')
+    x0 = torch.zeros(0, 256, 14, 14, device=DEV, requires_grad=True)
+    out = m(x0)
+    assert tuple(out.shape) == (0, 2, 28, 28) and out.requires_grad
+    maskrcnn_loss(out, torch.zeros(0, dtype=torch.int64, device=DEV), torch.zeros(0, 28, 28, device=DEV)).backward()
+    assert x0.grad is not None and x0.grad.shape == x0.shape
+    with torch.no_grad():
+        assert tuple(m(x0.detach()).shape) == (0, 2, 28, 28)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(3, 256, 14, 14, generator=g).relu().to(DEV)
+    bad = torch.tensor([1, 7, -1], device=DEV)
+    with torch.no_grad():
+        _, prob = m.mask_predictor.forward_from_nhwc(m.mask_head.forward_nhwc(x), bad, want_logits=False, want_prob=True)
+    assert torch.isfinite(prob[0]).all() and torch.isnan(prob[1]).all() and torch.isnan(prob[2]).all()
+    logits = m(x).detach().requires_grad_(True)
+    loss = maskrcnn_loss(logits, bad, torch.zeros(3, 28, 28, device=DEV))
+    assert torch.isnan(loss)
+    loss.backward()
+    assert float(logits.grad[1:].abs().max()) == 0.0
+
+
+def test_mask_branch_loads_a_reference_checkpoint_slice_strictly():
+    """ADVICE r2 (low) / INTEGRATION.md 2b: the `roi_heads.mask_head.*` / `roi_heads.mask_predictor.*` slice of a
+    reference-format checkpoint (torchvision's key names and shapes: model.py:17-25, train.py:115-117), saved with
+    torch.save and read back with weights_only=True, loads with strict=True, and the branch's own state_dict goes
+    the other way.  Parity unpinned (torchvision absent): names and shapes are torchvision's published ones."""
+    import io
+    from sfvos_amd import MaskBranch
+    want = {'mask_head.mask_fcn%d.%s' % (i, k): s for i in range(1, 5)
+            for k, s in (('weight', (256, 256, 3, 3)), ('bias', (256,)))}
+    want.update({'mask_predictor.conv5_mask.weight': (256, 256, 2, 2), 'mask_predictor.conv5_mask.bias': (256,),
+                 'mask_predictor.mask_fcn_logits.weight': (2, 256, 1, 1), 'mask_predictor.mask_fcn_logits.bias': (2,)})
+    g = torch.Generator().manual_seed(1)
+    ckpt = {'slow_fast.bn_f1.weight': torch.ones(32)}    # other keys of a SegmentationModel checkpoint are skipped
+    ckpt.update({'maskrcnn_model.roi_heads.' + k: torch.randn(s, generator=g) for k, s in want.items()})
+    buf = io.BytesIO()
+    torch.save(ckpt, buf)
+    buf.seek(0)
+    loaded = torch.load(buf, weights_only=True)
+    prefix = 'maskrcnn_model.roi_heads.'
+    sl = {k[len(prefix):]: v for k, v in loaded.items() if k.startswith(prefix)}
+    m = MaskBranch(256, 2, 'fp32')
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == want
+    m.load_state_dict(sl, strict=True)
+    o = OracleMaskBranch(256, 2)
+    o.load_state_dict(m.state_dict(), strict=True)
+    x = torch.randn(2, 256, 14, 14, generator=g).relu()
+    with torch.no_grad():
+        assert relmax(m.to(DEV)(x.to(DEV)).cpu(), o(x)) < 1e-4

@@ -236,11 +236,9 @@ def test_bf16_path_error_is_bounded(sp, fp):
 # ---- parity at the BENCHMARKED size, dtype and path (bench.py: (4,32), the 5-level DAVIS pyramid incl. level '0',
 # PackedClip hand-over, FusedSGD.attach gradient sink, overwrite + accumulate) against the CPU oracle run on this
 # box's host cores (model.py:118-165,369-374) -----------------------------------------------------------------
-@pytest.fixture(scope='module')
-def full_size_oracle():
+def _full_size_oracle(sp, fp):
     from sfvos_amd import davis_pyramid
     from oracle.slowfast_ref import _target
-    sp, fp = 4, 32
     pyr = davis_pyramid()
     gen = torch.Generator().manual_seed(63)
     # bf16-representable values, so the fp32 and the bf16 run (and the oracle) see the very same clip
@@ -254,7 +252,7 @@ def full_size_oracle():
     out = o.temporally_enhance_features([slow], [fast])
     loss = proxy_loss(out)
     loss.backward()
-    res = dict(sp=sp, fp=fp, pyr=pyr, fast=fast, loss=float(loss),
+    res = dict(sp=sp, fp=fp, pyr=pyr, fast=fast, slow=slow, loss=float(loss),
                out={k: v.detach().clone() for k, v in out.items()},
                grad={k: p.grad.detach().clone() for k, p in o.named_parameters()},
                target={k: _target(k, tuple(v.shape), v.device) for k, v in out.items()})
@@ -271,16 +269,34 @@ def full_size_oracle():
     return res
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
-def test_full_size_headline_config_matches_the_oracle(full_size_oracle, precision):
-    """fp32: fused maps, loss, BN running statistics, EVERY parameter gradient (whole tensors) and the parameters after
-    the SGD step within 1e-3 of the oracle (tensor scale); per-pixel argmax over the 256 fused channels identical at
-    every pixel whose top-2 margin in the oracle exceeds fp32 round-off (1e-4 of the map's scale; the pixels below
-    that margin are counted and printed -- at 85 932 pixels a handful of exact near-ties exist).
-    bf16 (the bench dtype, channel-group-major clip): the same quantities, errors measured and printed, bounded at
-    5e-2 (outputs, gradients), 2e-2 (loss); argmax agreement reported."""
+@pytest.fixture(scope='module')
+def full_size_oracle():
+    return _full_size_oracle(4, 32)
+
+
+@pytest.fixture(scope='module')
+def full_size_oracle_c4():
+    """BASELINE config 4: (sp, fp) = (4, 64) over ALL five DAVIS levels -- fast convs with kt = 22, the
+    laterals with kt = 41 / 21 (the 41-tap data gradient's weight image exceeds the LDS budget: L2-streaming variant;
+    the 41-tap forward exceeds the dedicated lateral kernel's budget), 64-frame level-'0' addressing (the clip is
+    2.8 GB in bf16, 5.6 GB in fp32)."""
+    return _full_size_oracle(4, 64)
+
+
+# Gates of the full-size comparison (each at most 2x what was measured on MI355X, see the prints of the tests):
+#   out: fused maps, max |a-b| / max|b|;  g3: layer-3 gradients (no ReLU behind them), (rel-L2, max entry / scale);
+#   g12: layer-1/2 gradients (behind ReLU masks: DESIGN.md section 2 and the mask-flip experiment below).
+FULL_GATES = {
+    ('c2', 'fp32'): dict(out=2e-5, loss=1e-5, g3=(1e-4, 1e-4), g12=(5e-3, 2e-2), stat=1e-4, param=1e-5),
+    ('c2', 'bf16'): dict(out=5e-2, loss=2e-2, g3=(2e-2, 2e-2), g12=(0.15, 0.3), stat=2e-2, param=1e-3),
+    ('c4', 'fp32'): dict(out=2e-5, loss=1e-5, g3=(1e-4, 1e-4), g12=(5e-3, 2e-2), stat=1e-4, param=1e-5),
+    ('c4', 'bf16'): dict(out=5e-2, loss=2e-2, g3=(2e-2, 2e-2), g12=(0.15, 0.3), stat=2e-2, param=1e-3),
+}
+
+
+def _check_full_size(r, precision, tag):
     from sfvos_amd import FusedSGD, MSEProxyLoss, PackedClip
-    r = full_size_oracle
+    gates = FULL_GATES[(tag, precision)]
     sp, fp, pyr = r['sp'], r['fp'], r['pyr']
     m, dev = build(sp, fp, precision)
     m.train()
@@ -297,23 +313,30 @@ def test_full_size_headline_config_matches_the_oracle(full_size_oracle, precisio
     loss.backward()                      # overwrite mode of the gradient sink
     loss_fn(m.enhance_packed(clip)).backward()   # accumulate mode
     assert m._grad_sink is opt
-    tol = FP32_TOL if precision == 'fp32' else 5e-2
     for k, v in out.items():
         ref = r['out'][k]
         got = v.detach().cpu()
         e = max_rel_err(got.numpy(), ref.numpy())
         top2 = ref.topk(2, dim=1).values
         margin = (top2[:, 0] - top2[:, 1])
-        safe = margin > 1e-4 * float(ref.abs().max())
+        scale = float(ref.abs().max())
+        err_px = (got - ref).abs().amax(1)          # this implementation's deviation at each pixel
         same = got.argmax(1) == ref.argmax(1)
-        print('%s full size level %s: max err / scale %.3e, rel-L2 %.3e, argmax agreement %.6f, %d of %d pixels inside '
-              'the round-off margin' % (precision, k, e, rel_err(got.numpy(), ref.numpy()), float(same.float().mean()),
-                                        int((~safe).sum()), safe.numel()))
-        assert e < tol, k
+        print('%s (%d,%d) full size level %s: max err / scale %.3e, rel-L2 %.3e, argmax agreement %.6f (%d of %d pixels '
+              'differ)' % (precision, sp, fp, k, e, rel_err(got.numpy(), ref.numpy()), float(same.float().mean()),
+                           int((~same).sum()), same.numel()))
+        assert e < gates['out'], k
         if precision == 'fp32':
-            assert bool(same[safe].all()), 'argmax differs outside the round-off margin (level %s)' % k
-    ltol = FP32_TOL if precision == 'fp32' else 2e-2
-    assert abs(loss.item() - r['loss']) < ltol * abs(r['loss']), (loss.item(), r['loss'])
+            # Where the argmax differs, the oracle's top-2 margin must be below the deviation of THAT pixel (x2: both
+            # channels move) -- i.e. the pixel is a near-tie that fp32 round-off decides -- and that deviation is itself
+            # gated above (measured 4e-6 of the scale): no exemption threshold is assumed.
+            for b_, h_, w_ in (~same).nonzero().tolist():
+                mg, ep = float(margin[b_, h_, w_]), float(err_px[b_, h_, w_])
+                print('   argmax differs at level %s pixel (%d,%d): oracle top-2 margin %.3e of scale, deviation there '
+                      '%.3e of scale' % (k, h_, w_, mg / scale, ep / scale))
+                assert mg <= 2.0 * ep and mg < gates['out'] * scale, (k, h_, w_, mg, ep)
+            assert int((~same).sum()) <= 1e-4 * same.numel(), k
+    assert abs(loss.item() - r['loss']) < gates['loss'] * abs(r['loss']), (loss.item(), r['loss'])
     gscale = max(float(v.abs().max()) for v in r['grad'].values())
     # gradients: rel-L2 and max-entry error of the whole tensors.
     # Layer 3 (no ReLU behind it): fp32 1e-4, bf16 2e-2 -- measured 1e-7..3e-6 and 1e-4..7e-3.
@@ -321,10 +344,9 @@ def test_full_size_headline_config_matches_the_oracle(full_size_oracle, precisio
     # (fp32) / ~1e-2 (bf16) lie within the other implementation's round-off of zero and get the opposite mask, which
     # moves sums over ~1 M positions by ~1e-3 (fp32, measured 0.3-1.6e-3 rel-L2) / ~7e-2 (bf16, measured 5-8e-2):
     # the error JUMPS between layer 3 and layer 2 and does not grow from layer 2 to layer 1 -- the signature of mask
-    # flips, not of accumulated arithmetic error (the fixtures, chosen for their ReLU margin, match at 2e-6 in fp32).
-    # Gates: fp32 5e-3 rel-L2 / 2e-2 per entry; bf16 0.15 / 0.3.
-    g_l2, g_max = (5e-3, 2e-2) if precision == 'fp32' else (0.15, 0.3)
-    g3_l2, g3_max = (1e-4, 1e-4) if precision == 'fp32' else (2e-2, 2e-2)
+    # flips, not of accumulated arithmetic error: test_full_size_fp32_relu_mask_flips_explain_the_gradient_error counts
+    # the flipped masks and shows the gradients agree at 1e-4 once both sides use the same masks.
+    (g_l2, g_max), (g3_l2, g3_max) = gates['g12'], gates['g3']
     rows = []
     for key, p in m.named_parameters():
         ref = 2.0 * r['grad'][key]
@@ -334,7 +356,7 @@ def test_full_size_headline_config_matches_the_oracle(full_size_oracle, precisio
             continue
         rows.append((key, rel_err(got.numpy(), ref.numpy()), max_rel_err(got.numpy(), ref.numpy())))
     for key, el2, emax in rows:
-        print('%s full size grad %-18s rel-L2 %.2e, max / scale %.2e' % (precision, key, el2, emax))
+        print('%s (%d,%d) full size grad %-18s rel-L2 %.2e, max / scale %.2e' % (precision, sp, fp, key, el2, emax))
     for key, el2, emax in rows:
         layer3 = key.split('.')[0] in ('fast_conv3', 'slow_conv3', 'bn_f3', 'bn_s3')
         assert el2 < (g3_l2 if layer3 else g_l2) and emax < (g3_max if layer3 else g_max), (key, el2, emax)
@@ -343,12 +365,103 @@ def test_full_size_headline_config_matches_the_oracle(full_size_oracle, precisio
         if key.endswith('num_batches_tracked'):
             assert int(b) == int(ref)
         else:
-            assert max_rel_err(b.cpu().numpy(), ref.numpy()) < (FP32_TOL if precision == 'fp32' else 2e-2), key
+            assert max_rel_err(b.cpu().numpy(), ref.numpy()) < gates['stat'], key
     opt.step()
     for key, p in m.named_parameters():
         ref = r['param'][key]
         d = float((p.detach().cpu() - ref).abs().max())
-        assert d <= (1e-5 if precision == 'fp32' else 1e-3) * float(ref.abs().max()) + 1e-9, (key, d)
+        assert d <= gates['param'] * float(ref.abs().max()) + 1e-9, (key, d)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_full_size_headline_config_matches_the_oracle(full_size_oracle, precision):
+    """The BENCHMARKED configuration (bench.py: (4,32), the 5-level DAVIS pyramid, PackedClip hand-over, FusedSGD.attach
+    gradient sink, overwrite + accumulate) against the CPU oracle run on this box's host cores.
+    fp32: fused maps, loss, BN running statistics, EVERY parameter gradient (whole tensors) and the parameters after
+    the SGD step against the oracle (gates FULL_GATES: at most 2x the measured error); per-pixel argmax over the 256
+    fused channels identical except at near-ties that fp32 round-off decides (each printed with its margin).
+    bf16 (the bench dtype, channel-group-major clip): the same quantities, errors measured and printed, bounded at
+    5e-2 (outputs, gradients), 2e-2 (loss); argmax agreement reported."""
+    _check_full_size(full_size_oracle, precision, 'c2')
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_full_size_config4_matches_the_oracle(full_size_oracle_c4, precision):
+    """BASELINE config 4 = (sp, fp) = (4, 64) at DAVIS size, all five levels, the same checks as the headline
+    configuration: this is the only place the kt = 22 frame-split conv, the kt = 41 lateral paths (weight image beyond
+    the LDS budget) and 64-frame level-'0' addressing run at full size against the oracle (Missing 5)."""
+    _check_full_size(full_size_oracle_c4, precision, 'c4')
+
+
+def _gpu_relu_masks(m, out, plan, pyr):
+    """The ReLU masks the GPU module used in the forward that produced `out` (dict of its fused maps, still on the
+    graph): the post-ReLU activations it stored for its backward, as {(level key, bn name): bool [1,C,T,H,W]}."""
+    state = next(iter(out.values())).grad_fn.state
+    masks = {}
+    for l in plan.layers:
+        if not l.relu:
+            continue
+        act = state.bufs[l.dst][:, l.dst_off: l.dst_off + l.c_out]
+        off = 0
+        for k, (h, w) in pyr:
+            n = l.t_out * h * w
+            a = act[off: off + n].reshape(1, l.t_out, h, w, l.c_out).permute(0, 4, 1, 2, 3)
+            masks[(k, l.bn)] = (a > 0).cpu()
+            off += n
+    return masks
+
+
+def test_full_size_fp32_relu_mask_flips_explain_the_gradient_error(full_size_oracle):
+    """VERDICT r2 (weak 1): the layer-1/2 gradients of the fp32 path differ from the oracle's by ~1e-3 rel-L2 at full
+    size while layer 3 agrees at 1e-6.  DESIGN.md attributes this to ReLU masks: a pre-activation within fp32 round-off
+    of zero lands on different sides in two correct implementations.  Evidence instead of argument:
+      (1) count the elements whose mask differs (GPU module vs oracle), per layer;
+      (2) re-run the ORACLE with the GPU module's masks (y * mask instead of relu(y): same forward values up to the
+          ~1e-6 pre-activations that flipped) and compare the gradients again: they must agree like layer 3 does."""
+    from sfvos_amd import MSEProxyLoss, PackedClip
+    r = full_size_oracle
+    sp, fp, pyr = r['sp'], r['fp'], r['pyr']
+    m, dev = build(sp, fp, 'fp32')
+    m.train()
+    levels = [r['fast'][k].to(dev).permute(0, 2, 3, 1).unsqueeze(0).contiguous() for k, _ in pyr]
+    clip = PackedClip.from_levels(levels, keys=[k for k, _ in pyr], layout='ndhwc')
+    del levels
+    loss_fn = MSEProxyLoss({k: v.to(dev) for k, v in r['target'].items()})
+    out = m.enhance_packed(clip)
+    masks = _gpu_relu_masks(m, out, m.plan, pyr)
+    loss_fn(out).backward()
+    torch.cuda.synchronize()
+    o = OracleSlowFastLayers(256, torch.device('cpu'), sp, fp)
+    o.load_state_dict(closed_form_state_dict(o))
+    o.train()
+    o.relu_masks = masks
+    proxy_loss(o.temporally_enhance_features([r['slow']], [r['fast']])).backward()
+    total = sum(v.numel() for v in masks.values())
+    flips = sum(o.relu_flips.values())
+    per_layer = {}
+    for (k, bn), n in o.relu_flips.items():
+        per_layer[bn] = per_layer.get(bn, 0) + n
+    print('fp32 full size: %d of %d ReLU masks differ between the GPU module and the oracle (%.2e): %s'
+          % (flips, total, flips / total, ', '.join('%s %d' % kv for kv in sorted(per_layer.items()))))
+    assert len(o.relu_flips) == len(masks)
+    assert flips <= 1e-4 * total, 'more mask flips than fp32 round-off explains'
+    worst_plain = worst_masked = 0.0
+    ref_plain = r['grad']
+    for key, p in m.named_parameters():
+        if key.endswith('conv1.bias') or key.endswith('conv2.bias') or key.endswith('conv3.bias'):
+            continue
+        got = p.grad.detach().cpu().numpy()
+        e_plain = rel_err(got, ref_plain[key].numpy())
+        e_mask = rel_err(got, dict(o.named_parameters())[key].grad.numpy())
+        layer3 = key.split('.')[0] in ('fast_conv3', 'slow_conv3', 'bn_f3', 'bn_s3')
+        print('fp32 full size grad %-18s rel-L2 vs oracle %.2e, vs oracle with the SAME masks %.2e' % (key, e_plain, e_mask))
+        if not layer3:
+            worst_plain, worst_masked = max(worst_plain, e_plain), max(worst_masked, e_mask)
+        assert e_mask < 1e-4, (key, e_mask)
+    print('fp32 full size: layer-1/2 gradients: worst rel-L2 %.2e against the oracle, %.2e once both sides use the same '
+          'ReLU masks' % (worst_plain, worst_masked))
+    if flips > 0:
+        assert worst_masked < 0.2 * worst_plain, 'the mask flips do not explain the gradient error'
 
 
 def _oracle_clip(sp, fp, fast_cpu, train=True):
@@ -625,8 +738,8 @@ def test_fp8_inference_path_error_is_measured_and_bounded(sp, fp):
         m8.temporally_enhance_features(slow, fast)
 
 
-@pytest.mark.parametrize('fused', [True, False])
-def test_c1_eight_centre_frames_trajectory_matches_the_oracle(fused):
+@pytest.mark.parametrize('fused,precision', [(True, 'fp32'), (False, 'fp32'), (True, 'bf16')])
+def test_c1_eight_centre_frames_trajectory_matches_the_oracle(fused, precision):
     """BASELINE config 1 as SURVEY.md 8d restates it: the reference's default (sp, fp) = (1, 1) (constants.py:7-8), 8
     consecutive centre frames = 8 sequential B = 1 calls of temporally_enhance_features, backward after each, SGD
     (lr 1e-3, momentum 0.9, wd 1e-4) after every 2nd (model.py:318-323,369-374; train.py:80): FOUR optimiser steps of
@@ -637,15 +750,22 @@ def test_c1_eight_centre_frames_trajectory_matches_the_oracle(fused):
     ReLU-mask flip agree to 3e-5, a clip with a flipped element (a pre-activation within fp32 rounding of zero) moves
     the gradients behind it by up to 4e-3 of their scale; BN running statistics 1e-5.
     (Five levels whose smallest has 24 positions: BatchNorm over the 2 positions of a 1x2 level is ill-conditioned in
-    BOTH implementations -- its backward is pure cancellation.)"""
+    BOTH implementations -- its backward is pure cancellation.)
+    bf16 (the bench dtype; VERDICT r2 weak 2: "no statement of how a bf16 run drifts over optimiser steps"): the same
+    trajectory with bf16 activations / fp32 master weights: the drift is MEASURED and printed -- per-clip loss error,
+    accumulated update, momentum buffers, running statistics -- and bounded at 2e-2 (loss), 0.25 rel-L2 (updates,
+    momentum), 2e-2 (running statistics)."""
     from sfvos_amd import FusedSGD, SlowFastLayers
+    bf16 = precision == 'bf16'
+    tol_loss, tol_u, tol_stat = (2e-2, 0.25, 2e-2) if bf16 else (1e-5, 1e-2, 1e-5)
+    loss_errs = []
     dev = torch.device('cuda:0')
     shapes = OrderedDict([('0', (24, 42)), ('1', (12, 21)), ('2', (6, 11)), ('3', (5, 8)), ('pool', (4, 6))])
     g = torch.Generator().manual_seed(63)
     frames = OrderedDict((k, torch.randn(8, 256, h, w, generator=g)) for k, (h, w) in shapes.items())
     torch.manual_seed(5)
     ref = OracleSlowFastLayers(256, torch.device('cpu'), 1, 1)
-    m = SlowFastLayers(256, dev, 1, 1, precision='fp32')
+    m = SlowFastLayers(256, dev, 1, 1, precision=precision)
     m.load_state_dict(ref.state_dict())
     m = m.to(dev)
     ref.train(); m.train()
@@ -662,7 +782,8 @@ def test_c1_eight_centre_frames_trajectory_matches_the_oracle(fused):
         loss = proxy_loss(m.temporally_enhance_features([win], [win]))
         loss.backward()
         lv, lr = float(loss.detach()), float(loss_r.detach())
-        assert abs(lv - lr) <= 1e-5 * abs(lr), (i, lv, lr)
+        loss_errs.append(abs(lv - lr) / abs(lr))
+        assert abs(lv - lr) <= tol_loss * abs(lr), (i, lv, lr)
         if i % 2 == 1:                                                           # model.py:372-374
             opt.step(); opt_r.step()
             opt.zero_grad(); opt_r.zero_grad()
@@ -673,24 +794,27 @@ def test_c1_eight_centre_frames_trajectory_matches_the_oracle(fused):
         return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
     zero_grad_bias = ('conv1.bias', 'conv2.bias', 'conv3.bias')   # conv bias in front of a train-mode BN: gradient 0
-    worst_u = worst_m = 0.0
+    worst_u = worst_m = worst_s = 0.0
     ref_p = dict(ref.named_parameters())
     sd_r, sd = opt_r.state_dict()['state'], opt.state_dict()['state']
     for i, (name, p) in enumerate(m.named_parameters()):
         if name.endswith(zero_grad_bias):
             # the update is weight decay on round-off: the parameter itself stays within 1e-6 of its scale
             a, b = p.detach().cpu().double(), ref_p[name].detach().double()
-            assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-9, name
+            assert float((a - b).abs().max()) <= (1e-4 if bf16 else 1e-6) * float(b.abs().max()) + 1e-9, name
             continue
         eu = rel_l2(p.detach().cpu() - p0[name], ref_p[name].detach() - p0[name])
         em = rel_l2(sd[i]['momentum_buffer'].cpu(), sd_r[i]['momentum_buffer'])
         worst_u, worst_m = max(worst_u, eu), max(worst_m, em)
-        assert eu < 1e-2 and em < 1e-2, (name, eu, em)
+        assert eu < tol_u and em < tol_u, (name, eu, em)
     ref_b = dict(ref.named_buffers())
     for name, bufr in m.named_buffers():
         if name.endswith('num_batches_tracked'):
             assert int(bufr) == int(ref_b[name]) == 8 * len(shapes)
         else:
-            assert max_rel_err(bufr.cpu().numpy(), ref_b[name].numpy()) < 1e-5, name
-    print('C1 trajectory (%s): 8 clips, 4 optimiser steps: worst update rel-L2 %.2e, worst momentum buffer %.2e'
-          % ('FusedSGD + sink' if fused else 'torch.optim.SGD', worst_u, worst_m))
+            worst_s = max(worst_s, max_rel_err(bufr.cpu().numpy(), ref_b[name].numpy()))
+            assert max_rel_err(bufr.cpu().numpy(), ref_b[name].numpy()) < tol_stat, name
+    print('C1 trajectory (%s, %s): 8 clips, 4 optimiser steps: per-clip loss error %s; worst update rel-L2 %.2e, worst '
+          'momentum buffer %.2e, worst running statistic %.2e'
+          % ('FusedSGD + sink' if fused else 'torch.optim.SGD', precision, ' '.join('%.1e' % e for e in loss_errs),
+             worst_u, worst_m, worst_s))
