@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SFVOS_LIB') or os.path.join(_HERE, 'csrc', 'libsfvos.so')  # SFVOS_LIB: A/B builds
 
 F32, BF16, FP8 = 0, 1, 2
+ABI_REVISION = 300   # the revision of include/sfvos.h this binding mirrors
 MAX_LEVELS = 8
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -139,6 +140,10 @@ SIGNATURES = {
     'sfvos_deconv2x2_dgrad': (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     'sfvos_deconv2x2_wgrad_workspace_bytes': (C.c_size_t, [i32, i32, i32, i32, i32]),
     'sfvos_deconv2x2_wgrad': (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
+    'sfvos_roi_levels': (i32, [vp, i32, i32, i32, f32, f32, f32, vp, vp]),
+    'sfvos_roi_align_workspace_bytes': (C.c_size_t, [i32]),
+    'sfvos_roi_align': (i32, [vp, i32, i32, i32, i32, vp, vp, i32, i32, f32, i32, i32, vp, vp, vp]),
+    'sfvos_roi_align_bwd': (i32, [vp, i32, i32, i32, i32, vp, vp, i32, i32, f32, i32, i32, vp, vp, i32, vp]),
 }
 
 _lib = None
@@ -163,10 +168,10 @@ def load():
     n = lib.sfvos_abi_sizes(sizes, 7)
     mine = [C.sizeof(ConvDesc), C.sizeof(Pyramid), C.sizeof(Levels), C.sizeof(MseTable), C.sizeof(BnRunning),
             C.sizeof(PackItem), C.sizeof(PlanarLevel)]
-    if lib.sfvos_version() < 201 or n != 7 or list(sizes) != mine:
-        raise RuntimeError('sfvos_amd: %s is ABI revision %d with struct sizes %s, this binding expects revision >= 201 '
+    if lib.sfvos_version() < ABI_REVISION or n != 7 or list(sizes) != mine:
+        raise RuntimeError('sfvos_amd: %s is ABI revision %d with struct sizes %s, this binding expects revision >= %d '
                            'and %s -- rebuild with `python __graft_entry__.py`' % (LIB_PATH, lib.sfvos_version(),
-                                                                                   list(sizes)[:n], mine))
+                                                                                   list(sizes)[:n], ABI_REVISION, mine))
     _lib = lib
     return lib
 

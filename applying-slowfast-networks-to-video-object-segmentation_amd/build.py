@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libsfvos.so')
-SOURCES = ['runtime.hip', 'elementwise.hip', 'batchnorm.hip', 'conv3d.hip', 'wgrad.hip', 'lateral.hip', 'maskhead.hip']
+SOURCES = ['runtime.hip', 'elementwise.hip', 'batchnorm.hip', 'conv3d.hip', 'wgrad.hip', 'lateral.hip', 'lateral_wgrad.hip', 'maskhead.hip', 'roialign.hip']
 HEADERS = ['common.h', 'elt_util.h']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
@@ -17,32 +17,36 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, diag=False):
+    """diag=True: libsfvos_diag.so, compiled with -DSFVOS_DIAG (timing-only switches and tuning overrides read from the
+    environment; tools/diag only, never loaded by the package unless SFVOS_LIB names it)."""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    flags = FLAGS + (['-DSFVOS_DIAG'] if diag else [])
+    lib = LIB.replace('libsfvos.so', 'libsfvos_diag.so') if diag else LIB
     deps = [os.path.join(CSRC, h) for h in HEADERS]
     deps.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), 'include', 'sfvos.h'))
 
     def compile_one(src):
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace('.hip', '.o'))
+        o = os.path.join(CSRC, src.replace('.hip', '.diag.o' if diag else '.o'))
         if force or _newer(s, o) or any(_newer(d, o) for d in deps):
-            cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+            cmd = [hipcc] + flags + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.run(cmd, check=True)
             return o, True
         return o, False
 
-    with ThreadPoolExecutor(max_workers=7) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         results = list(ex.map(compile_one, SOURCES))
     objs = [o for o, _ in results]
-    if force or any(ch for _, ch in results) or not os.path.exists(LIB):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    if force or any(ch for _, ch in results) or not os.path.exists(lib):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose=True))
+    print(build(force='--force' in sys.argv, verbose=True, diag='--diag' in sys.argv))

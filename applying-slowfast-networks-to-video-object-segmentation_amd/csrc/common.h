@@ -129,6 +129,14 @@ int lateral_fwd_rows(const sfvos_conv_desc* d, int level);
 int lateral_fwd_launch(const sfvos_conv_desc* d, const void* x, const void* w_packed, const float* bias, void* y,
                        float* stat_part, hipStream_t stream);
 
+// lateral_wgrad.hip: weight gradient of the lateral convs; -1 / 0 = shape not covered
+size_t lateral_wgrad_workspace_bytes(const sfvos_conv_desc* d);
+int lateral_wgrad_try(const sfvos_conv_desc* d, const void* x, const void* dy, float* grad_w, int accumulate,
+                      void* workspace, hipStream_t stream);
+// wgrad.hip: grad_w[n][c][dt][tap] (=|+=) sum over the psplit slabs [n][dt][tap][c], fixed order
+int launch_wgrad_reduce(const float* slab, int psplit, int c_out, int c_in, int kt, int taps, float* grad_w,
+                        int accumulate, hipStream_t stream);
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

@@ -26,29 +26,40 @@ struct LatLevels {
   long long ypos[SFVOS_MAX_LEVELS];
 };
 
-constexpr int LAT_DG_NW = 8;       // waves per workgroup of the data-gradient kernel
 constexpr int LAT_DG_PF = 3;       // output frames whose previous contents are in flight (accumulate mode)
-constexpr int LAT_DG_MAX_LDS = 80 * 1024;  // weight image: two workgroups per compute unit
+constexpr int LAT_DG_MAX_LDS = 80 * 1024;   // weight image up to here: 8-wave workgroups, two per compute unit
+constexpr int LAT_DG_BIG_LDS = 160 * 1024;  // ... up to here: 12-wave workgroups, one per compute unit
+// MODE: 0 = weight fragments streamed from L2 (no LDS), 1 = image in LDS (<= 80 KB), 2 = image in LDS (<= 160 KB),
+// 3 = all taps but the last in LDS (160 KB) and the last tap's fragments in registers: the (4,64) configuration's
+// kt = 41 x 64 reduction channels is 164 KB, one tap more than a compute unit's LDS holds.
+__host__ __device__ constexpr int lat_dg_nw(int mode) { return mode >= 2 ? 12 : 8; }
 
 struct LatArgs {
   const char* dy;   // conv "x": t_in frames, c_in channels, pitch ld_dy
   const char* wp;   // packed data-gradient image
   char* dx;         // conv "y": t_out = t_in + kt - 1 frames, 32 channels, pitch ld_dx
   int t_in, t_out, kt, ld_dy, ld_dx, accumulate, batch, n_waves;
+  int kl;           // taps of the weight image held in LDS (MODE 1, 2: kt; MODE 3: kt - 1)
   LatLevels lv;
 };
 
 // KS = c_in / 32 reduction chunks, TIN = frames of dy (compile-time: the fragments are a register array)
 // WL: the weight image fits the LDS budget (<= 80 KB: kt <= 20 for 64 channels) and is staged there; else (the (4,64)
 // configuration's kt = 41) the fragments stream from L2 as in round 1.
-template <int KS, int TIN, bool ACC, bool WL>
-__global__ __launch_bounds__(64 * LAT_DG_NW) void lateral_dgrad_kernel(LatArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // the weight image: [chunk][dt][j][c][16 B]
+template <int KS, int TIN, bool ACC, int MODE>
+__global__ __launch_bounds__(64 * lat_dg_nw(MODE)) void lateral_dgrad_kernel(LatArgs a) {
+  constexpr bool WL = MODE >= 1, WREG = MODE == 3;
+  constexpr int LAT_DG_NW = lat_dg_nw(MODE);
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // the weight image: [chunk][dt < kl][j][c][16 B]
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int KL = WL ? a.kl : a.kt;   // temporal stride of the image the fragments are read from
   // weight image -> LDS by LDS-DMA: wave wv copies the 1 KB pieces wv, wv + NW, ... (lane i lands at +16 i)
   if (WL)
-    for (int q = wv; q < KS * a.kt * 2; q += LAT_DG_NW) glds16(a.wp + q * 1024 + lane * 16, smem + q * 1024);
+    for (int q = wv; q < KS * KL * 2; q += LAT_DG_NW) {
+      const int ks = q / (KL * 2);   // the taps [0, KL) of each reduction chunk are contiguous in the packed image
+      glds16(a.wp + (ks * a.kt * 2 + (q - ks * KL * 2)) * 1024 + lane * 16, smem + q * 1024);
+    }
   const bool live = (int)blockIdx.x * LAT_DG_NW + wv < a.n_waves;  // idle waves redo the last tile without storing
   const int tile = live ? blockIdx.x * LAT_DG_NW + wv : a.n_waves - 1;
   int lvl = 0;
@@ -75,6 +86,14 @@ __global__ __launch_bounds__(64 * LAT_DG_NW) void lateral_dgrad_kernel(LatArgs a
       }
 
   const char* wl = (WL ? (const char*)smem : a.wp) + (g * 32 + p16) * 16;  // lane part of a weight fragment address
+  u32x4 wreg[WREG ? KS : 1][2];   // MODE 3: the fragments of tap kt - 1
+  if (WREG) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        wreg[ks][mt] = *(const u32x4*)(a.wp + (g * 32 + p16) * 16 + (long long)(((ks * a.kt + KL) * 4) * 32 + mt * 16) * 16);
+  }
   // this lane's 4-channel runs of an output frame: [pixel half][channel half].  Loads of the previous contents are
   // unconditional (pixels beyond the level and frames beyond the clip clamped to the last valid one): a branch
   // around a load makes the compiler wait for every outstanding load before the next use.
@@ -124,7 +143,9 @@ __global__ __launch_bounds__(64 * LAT_DG_NW) void lateral_dgrad_kernel(LatArgs a
           for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-              const u32x4 w = *(const u32x4*)(wl + (long long)(((ks * a.kt + dt) * 4) * 32 + mt * 16) * 16);
+              u32x4 w;
+              if (WREG && dt == KL) w = wreg[WREG ? ks : 0][mt];   // wave-uniform
+              else w = *(const u32x4*)(wl + (long long)(((ks * KL + dt) * 4) * 32 + mt * 16) * 16);
 #pragma unroll
               for (int nt = 0; nt < 2; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w),
@@ -162,8 +183,6 @@ __global__ __launch_bounds__(64 * LAT_DG_NW) void lateral_dgrad_kernel(LatArgs a
 // (sfvos_pack_weights_fwd: [dt][j][n][8]: one 16-byte run per lane, 16 lanes = 256 contiguous bytes of LDS), B = 32
 // channels x 16 pixels of x.  Per-channel (sum, sum of squares) of the fp32 results leave as ONE row per workgroup
 // (BatchNorm statistics); workgroups are level-aligned so that a row belongs to one level.
-constexpr int LAT_PF = 4;  // input frames in flight per wave
-
 struct LatFwdArgs {
   const char* x; const char* wp; const float* bias; char* y; float* stat_part;
   int t_in, t_alloc, t_offset, t_out, kt, ld_x, ld_y, batch, relu;
@@ -174,13 +193,17 @@ struct LatFwdArgs {
 };
 
 // NW waves per workgroup; three waves per SIMD (at most 168 registers) so that the clip is ONE round of workgroups
-template <int TOUT, int NW>
+// WREG: the weight image has ONE tap more than the 40 that 160 KB of LDS hold (the (4,64) configuration's kt = 41): the
+// fragments of tap 40 stay in registers (16 per lane) and one input frame less is kept in flight.
+template <int TOUT, int NW, bool WREG>
 __global__ __launch_bounds__(64 * NW, 3) void lateral_fwd_kernel(LatFwdArgs a) {
+  constexpr int LAT_PF = WREG ? 3 : 4;  // input frames in flight per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [kt][4 chunks][64 n][16 B]; later [NW][2][64] floats
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int KL = WREG ? a.kt - 1 : a.kt;   // taps held in LDS
   // weight image -> LDS by LDS-DMA: wave wv copies the 1 KB pieces wv, wv + NW, ... (lane i lands at +16 i)
-  for (int q = wv; q < a.kt * 4; q += NW) glds16(a.wp + q * 1024 + lane * 16, smem + q * 1024);
+  for (int q = wv; q < KL * 4; q += NW) glds16(a.wp + q * 1024 + lane * 16, smem + q * 1024);
   int lvl = 0;
 #pragma unroll
   for (int l = 1; l < SFVOS_MAX_LEVELS; ++l)
@@ -217,6 +240,11 @@ __global__ __launch_bounds__(64 * NW, 3) void lateral_fwd_kernel(LatFwdArgs a) {
   };
 #pragma unroll
   for (int u = 0; u < LAT_PF; ++u) load_x(u, xf[u]);
+  u32x4 wreg[WREG ? 4 : 1];   // the fragments of tap KL
+  if (WREG) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) wreg[mt] = *(const u32x4*)(a.wp + (g * 64 + p16) * 16 + (KL * 256 + mt * 16) * 16);
+  }
   __syncthreads();  // weight image complete
   const char* wl = smem + (g * 64 + p16) * 16;
   for (int t0 = 0; t0 < a.t_in; t0 += LAT_PF) {
@@ -230,7 +258,9 @@ __global__ __launch_bounds__(64 * NW, 3) void lateral_fwd_kernel(LatFwdArgs a) {
           if (dt < 0 || dt >= a.kt) continue;  // wave-uniform
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) {
-            const u32x4 w = *(const u32x4*)(wl + (dt * 256 + mt * 16) * 16);
+            u32x4 w;
+            if (WREG && dt == KL) w = wreg[WREG ? mt : 0];   // wave-uniform
+            else w = *(const u32x4*)(wl + (dt * 256 + mt * 16) * 16);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
               acc[f][nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w),
@@ -305,9 +335,10 @@ __global__ __launch_bounds__(64 * NW, 3) void lateral_fwd_kernel(LatFwdArgs a) {
   }
 }
 
-constexpr int LAT_FWD_MAX_KT = 20;  // 80 KB of weights: two workgroups per compute unit
-// waves per workgroup: 12 waves per compute unit as 3 x 4 (weights <= 52 KB) or 2 x 6
-static int lateral_fwd_nw(const sfvos_conv_desc* d) { return d->kt <= 13 ? 4 : 6; }
+constexpr int LAT_FWD_LDS_KT = 40;                  // taps 160 KB of LDS hold (4 KB each)
+constexpr int LAT_FWD_MAX_KT = LAT_FWD_LDS_KT + 1;  // ... plus one tap in registers
+// waves per workgroup: 12 waves per compute unit as 3 x 4 (weights <= 52 KB), 2 x 6 (<= 80 KB) or 1 x 12
+static int lateral_fwd_nw(const sfvos_conv_desc* d) { return d->kt <= 13 ? 4 : d->kt <= 20 ? 6 : 12; }
 
 // The shapes the forward kernel covers (make_plan asks: the statistics rows are per workgroup of THIS kernel).
 bool lateral_fwd_applies(const sfvos_conv_desc* d) {
@@ -346,17 +377,22 @@ int lateral_fwd_launch(const sfvos_conv_desc* d, const void* x, const void* w_pa
   a.wg_begin[SFVOS_MAX_LEVELS] = (int)wg;
   SFVOS_REQUIRE(wg > 0 && wg < (1ll << 30), "conv: grid out of range");
   const int nw = lateral_fwd_nw(d);
-  const int lds = a.kt * 4096 > nw * 512 ? a.kt * 4096 : nw * 512;
+  const bool wreg = a.kt > LAT_FWD_LDS_KT;
+  const int kl = wreg ? a.kt - 1 : a.kt;
+  const int lds = kl * 4096 > nw * 512 ? kl * 4096 : nw * 512;
   const dim3 grid((unsigned)wg);
-#define SFVOS_LATF(TOUTv, NWv)                                                                              \
-  if (a.t_out == TOUTv && nw == NWv) {                                                                      \
-    auto kern = lateral_fwd_kernel<TOUTv, NWv>;                                                             \
+#define SFVOS_LATF(TOUTv, NWv, WREGv)                                                                       \
+  if (a.t_out == TOUTv && nw == NWv && wreg == WREGv) {                                                     \
+    auto kern = lateral_fwd_kernel<TOUTv, NWv, WREGv>;                                                      \
     static LdsAttrOnce once;                                                                                \
-    if (int rc = once.ensure((const void*)kern, LAT_FWD_MAX_KT * 4096, "lateral_fwd")) return rc;           \
+    if (int rc = once.ensure((const void*)kern, LAT_FWD_LDS_KT * 4096, "lateral_fwd")) return rc;           \
     hipLaunchKernelGGL(kern, grid, dim3(64 * NWv), lds, stream, a);                                         \
     return check_launch("lateral_fwd");                                                                     \
   }
-  SFVOS_LATF(1, 4) SFVOS_LATF(2, 4) SFVOS_LATF(3, 4) SFVOS_LATF(1, 6) SFVOS_LATF(2, 6) SFVOS_LATF(3, 6)
+  SFVOS_LATF(1, 4, false) SFVOS_LATF(2, 4, false) SFVOS_LATF(3, 4, false)
+  SFVOS_LATF(1, 6, false) SFVOS_LATF(2, 6, false) SFVOS_LATF(3, 6, false)
+  SFVOS_LATF(1, 12, false) SFVOS_LATF(2, 12, false) SFVOS_LATF(3, 12, false)
+  SFVOS_LATF(1, 12, true) SFVOS_LATF(2, 12, true) SFVOS_LATF(3, 12, true)
 #undef SFVOS_LATF
   return SFVOS_E_ARG;
 }
@@ -388,20 +424,28 @@ int lateral_dgrad_try(const sfvos_conv_desc* d, const void* x, const void* w_pac
   a.lv.wave_begin[SFVOS_MAX_LEVELS] = (int)waves;
   if (waves <= 0 || waves >= (1ll << 30)) return -1;
   a.n_waves = (int)waves;
-  const dim3 grid((unsigned)ceil_div64(waves, LAT_DG_NW)), block(64 * LAT_DG_NW);
   const int ks = d->c_in / 32;
   const int image = ks * d->kt * 2048;  // the packed data-gradient image
-  const bool wl = image <= LAT_DG_MAX_LDS;
-  const int lds = wl ? image : 0;
-#define SFVOS_LAT3(KSv, TINv, ACCv, WLv)                                                           \
-  if (ks == KSv && d->t_in == TINv && (d->accumulate != 0) == ACCv && wl == WLv) {                 \
-    auto kern = lateral_dgrad_kernel<KSv, TINv, ACCv, WLv>;                                        \
+  // where the weight fragments come from: LDS (two small workgroups or one big one per compute unit), LDS + the last tap
+  // in registers, or -- images beyond that -- streamed from L2
+  int mode = 0;
+  a.kl = d->kt;
+  if (image <= LAT_DG_MAX_LDS) mode = 1;
+  else if (image <= LAT_DG_BIG_LDS) mode = 2;
+  else if (image - ks * 2048 <= LAT_DG_BIG_LDS) { mode = 3; a.kl = d->kt - 1; }
+  const int nw = lat_dg_nw(mode);
+  const dim3 grid((unsigned)ceil_div64(waves, nw)), block(64 * nw);
+  const int lds = mode ? ks * a.kl * 2048 : 0;
+#define SFVOS_LAT3(KSv, TINv, ACCv, MODEv)                                                         \
+  if (ks == KSv && d->t_in == TINv && (d->accumulate != 0) == ACCv && mode == MODEv) {             \
+    auto kern = lateral_dgrad_kernel<KSv, TINv, ACCv, MODEv>;                                      \
     static LdsAttrOnce once;                                                                       \
-    if (int rc = once.ensure((const void*)kern, LAT_DG_MAX_LDS, "lateral_dgrad")) return rc;       \
+    if (int rc = once.ensure((const void*)kern, LAT_DG_BIG_LDS, "lateral_dgrad")) return rc;       \
     hipLaunchKernelGGL(kern, grid, block, lds, stream, a);                                         \
     return check_launch("lateral_dgrad");                                                          \
   }
-#define SFVOS_LAT2(KSv, TINv, ACCv) SFVOS_LAT3(KSv, TINv, ACCv, true) SFVOS_LAT3(KSv, TINv, ACCv, false)
+#define SFVOS_LAT2(KSv, TINv, ACCv) \
+  SFVOS_LAT3(KSv, TINv, ACCv, 0) SFVOS_LAT3(KSv, TINv, ACCv, 1) SFVOS_LAT3(KSv, TINv, ACCv, 2) SFVOS_LAT3(KSv, TINv, ACCv, 3)
 #define SFVOS_LAT(KSv, TINv) SFVOS_LAT2(KSv, TINv, true) SFVOS_LAT2(KSv, TINv, false)
   SFVOS_LAT(2, 1) SFVOS_LAT(2, 2) SFVOS_LAT(2, 3) SFVOS_LAT(1, 1) SFVOS_LAT(1, 2) SFVOS_LAT(1, 3)
 #undef SFVOS_LAT

@@ -43,7 +43,7 @@ int device_cu_count() {
 
 }  // namespace sfvos
 
-extern "C" int sfvos_version(void) { return 201; }
+extern "C" int sfvos_version(void) { return 300; }
 
 extern "C" int sfvos_abi_sizes(int* sizes, int n) {
   const int v[7] = {(int)sizeof(sfvos_conv_desc), (int)sizeof(sfvos_pyramid), (int)sizeof(sfvos_levels),

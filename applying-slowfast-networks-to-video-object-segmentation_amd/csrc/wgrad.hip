@@ -45,7 +45,9 @@ struct WgradArgs {
   WgradLevels lv;
 };
 
-template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R>
+// NXS: x tiles a stage may copy ahead (2: one frame per stage is new when t_out > 1; DG: a conv with ONE output frame
+// re-uses nothing between stages -- every stage needs DG new frames -- so the ring holds two stages, R = 2 DG)
+template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS = 2>
 struct WgradCfg {
   static constexpr int CE = Elt<DT>::CE;
   static constexpr int SPP = 32 / CE;            // 16-B slots per pixel per 32-channel tile
@@ -76,9 +78,9 @@ __device__ __forceinline__ u32x4 join(const u32x2& lo, const u32x2& hi) {
 }
 
 // (the body is a __device__ function: the buffer-descriptor type it uses exists only in device compilation)
-template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R>
+template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
-  typedef WgradCfg<DT, TAPS, NTN, NTC, DG, TH, R> C;
+  typedef WgradCfg<DT, TAPS, NTN, NTC, DG, TH, R, NXS> C;
   constexpr int CE = C::CE, ES = 16 / CE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const xbase = smem;
@@ -214,23 +216,28 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   // runs, up to two more x tiles (nx) and the next dy frame (ndy) are copied, piece by piece between MFMA groups.
   constexpr int TROWS = TAPS == 9 ? 3 : 1, TCOLS = TAPS == 9 ? 3 : 1;
   constexpr int NSTEP = TH * TROWS;
-  static_assert(2 * NXP + NDY + 2 <= NSTEP || DT != SFVOS_BF16, "the copies of a stage must fit between its MFMA steps");
+  constexpr int NCOPY = NXS * NXP + NDY;   // copy slots of a stage: [x tile 0 pieces] ... [x tile NXS-1 pieces][dy pieces]
+  static_assert(NCOPY + 2 <= 2 * NSTEP || DT != SFVOS_BF16, "the copies of a stage must fit between its MFMA steps");
   auto compute = [&](int s, int q0, int nx, bool ndy) {
     const char* dyb = dybase + (s & 1) * C::DY_BYTES + nt * (C::NPOS * C::ROWB);
     const char* xb = xbase + ((q0 + dg) % R) * C::X_BYTES + ct * (C::XT_SLOTS * 16);
     Copy cx, cd;
-    // copy schedule by step: [0] begin x#1, [0..NXP) its pieces, [NXP] begin x#2, then its pieces, then dy
-    auto copies = [&](int step) {
-      if (step == 0 && nx > 0) begin_x(cx);
-      if (step < NXP) { if (nx > 0) x_piece(cx, step); return; }
-      if (step == NXP && nx > 1) begin_x(cx);
-      if (step < 2 * NXP) { if (nx > 1) x_piece(cx, step - NXP); return; }
-      if (step == 2 * NXP && ndy) begin_dy(cd, s + 1);
-      if (step < 2 * NXP + NDY) { if (ndy) dy_piece(cd, step - 2 * NXP); return; }
+    // copy schedule by slot: x tile i = slot / NXP begins at slot i NXP, its pieces follow; then the dy frame
+    auto copies = [&](int slot) {
+      if (slot < NXS * NXP) {
+        const int i = slot / NXP, pc = slot - i * NXP;
+        if (i < nx) {
+          if (pc == 0) begin_x(cx);
+          x_piece(cx, pc);
+        }
+        return;
+      }
+      if (slot == NXS * NXP && ndy) begin_dy(cd, s + 1);
+      if (slot < NCOPY) { if (ndy) dy_piece(cd, slot - NXS * NXP); return; }
     };
     if (!wave_live) {  // nothing to multiply (tap / channel tile past the tensor): just feed the copies
 #pragma unroll
-      for (int step = 0; step < 2 * NXP + NDY; ++step) copies(step);
+      for (int slot = 0; slot < NCOPY; ++slot) copies(slot);
       return;
     }
     if constexpr (DT == SFVOS_BF16) {
@@ -245,7 +252,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
         // the dy fragments of rows rr, rr-1, rr-2 stay in a 4-deep rolling buffer.  76 transposed reads per stage
         // instead of 160.  Fragments of step rr+1 are read while the MFMAs of step rr run (pinned order).
         constexpr int NROW = TH + 2;
-        static_assert(2 * NXP + NDY <= NROW, "the copies of a stage must fit between its row steps");
+        constexpr int CPS = (NCOPY + NROW - 1) / NROW;   // copy slots per row step
         u32x2 ar[4][2], br[2][3][2];
         auto load = [&](int rr) {
           if (rr < TH) {
@@ -273,13 +280,15 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
               Mma<SFVOS_BF16>::run(acc[dh * 3 + dw], av, join(br[rr & 1][dw][0], br[rr & 1][dw][1]));
           }
           __builtin_amdgcn_sched_barrier(0);
-          copies(rr);
+#pragma unroll
+          for (int u = 0; u < CPS; ++u) copies(rr * CPS + u);
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
       // step = (ty, dh): one A fragment per ty, TCOLS B fragments per step; a PD-deep register pipeline
       // reads the fragments of step+PD-1 while this step's MFMAs run (order pinned with sched_barrier)
       constexpr int PD = 3;
+      static_assert(NCOPY <= NSTEP, "one copy slot per MFMA step in this path");
       u32x2 ar[PD][2], br[PD][TCOLS][2];
       auto load = [&](int step, int buf) {
         const int ty = step / TROWS, dh = step % TROWS;
@@ -311,7 +320,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
       }
     } else {
 #pragma unroll
-      for (int step = 0; step < 2 * NXP + NDY; ++step) copies(step);
+      for (int slot = 0; slot < NCOPY; ++slot) copies(slot);
 #pragma unroll
       for (int ty = 0; ty < TH; ++ty) {
 #pragma unroll
@@ -347,7 +356,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // loads q < q0 + R overwrite frames that no stage >= s reads
-    const int nx = max(0, min(2, min(QT, q0 + R) - xi_q));
+    const int nx = max(0, min(NXS, min(QT, q0 + R) - xi_q));
     compute(s, q0, nx, s + 1 < S);
     ++q0;
     if (++fo == a.t_out) { fo = 0; q0 += dt_live - 1; }
@@ -366,39 +375,68 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   }
 }
 
-template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R>
+template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS = 2>
 __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
-  wgrad_body<DT, TAPS, NTN, NTC, DG, TH, R>(a);
+  wgrad_body<DT, TAPS, NTN, NTC, DG, TH, R, NXS>(a);
 }
 
 // grad_w[n][c][dt][tap] (=|+=) sum_ps slab[ps][n][dt][tap][c]
-// block = 64 consecutive c x 4 (n,dt,tap) rows: coalesced slab reads along c.
+// block = 64 consecutive slab elements (16 lanes x 16-byte loads, coalesced along c) x 16 groups of splits: group g adds
+// the splits g, g+16, g+32, ... in order (two running sums), the sixteen group sums are combined in a fixed order
+// through LDS -- deterministic, and enough loads in flight to stream the slabs (the reduction of 256 slabs used to take as
+// long as the kernel that wrote them).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int psplit, int c_out,
                                                            int c_in, int kt, int taps, float* grad_w, int accumulate) {
-  const long long total = (long long)c_out * c_in * kt * taps;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    long long k = i;
-    const int c = (int)(k % c_in); k /= c_in;
-    const int tap = (int)(k % taps); k /= taps;
-    const int dt = (int)(k % kt); k /= kt;
-    const int n = (int)k;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int p = 0;
-    for (; p + 4 <= psplit; p += 4) {
-      s0 += slab[(long long)p * total + i];
-      s1 += slab[(long long)(p + 1) * total + i];
-      s2 += slab[(long long)(p + 2) * total + i];
-      s3 += slab[(long long)(p + 3) * total + i];
+  __shared__ float red[16][64];
+  const long long total = (long long)c_out * c_in * kt * taps;   // a multiple of 32 (c_in is)
+  const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+  for (long long base = (long long)blockIdx.x * 64; base < total; base += (long long)gridDim.x * 64) {
+    const long long i = base + 4 * l;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    if (i < total) {
+      int p = g;
+      for (; p + 16 < psplit; p += 32) {
+        s0 += *(const f32x4*)(slab + (long long)p * total + i);
+        s1 += *(const f32x4*)(slab + (long long)(p + 16) * total + i);
+      }
+      for (; p < psplit; p += 16) s0 += *(const f32x4*)(slab + (long long)p * total + i);
     }
-    for (; p < psplit; ++p) s0 += slab[(long long)p * total + i];
-    const float s = (s0 + s1) + (s2 + s3);
-    float* dst = grad_w + (((long long)n * c_in + c) * kt + dt) * taps + tap;
-    *dst = accumulate ? *dst + s : s;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[g][4 * l + e] = s0[e] + s1[e];
+    __syncthreads();
+    const long long j = base + threadIdx.x;
+    if (threadIdx.x < 64 && j < total) {
+      const int t = threadIdx.x;
+      const float q0 = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+      const float q1 = (red[4][t] + red[5][t]) + (red[6][t] + red[7][t]);
+      const float q2 = (red[8][t] + red[9][t]) + (red[10][t] + red[11][t]);
+      const float q3 = (red[12][t] + red[13][t]) + (red[14][t] + red[15][t]);
+      const float sum = (q0 + q1) + (q2 + q3);
+      long long k = j;
+      const int c = (int)(k % c_in); k /= c_in;
+      const int tap = (int)(k % taps); k /= taps;
+      const int dt = (int)(k % kt); k /= kt;
+      const int n = (int)k;
+      float* dst = grad_w + (((long long)n * c_in + c) * kt + dt) * taps + tap;
+      *dst = accumulate ? *dst + sum : sum;
+    }
+    __syncthreads();
   }
 }
 
+int launch_wgrad_reduce(const float* slab, int psplit, int c_out, int c_in, int kt, int taps, float* grad_w,
+                        int accumulate, hipStream_t stream) {
+  const long long total = (long long)c_out * c_in * kt * taps;
+  long long rgrid = ceil_div64(total, 64);
+  if (rgrid > 8192) rgrid = 8192;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rgrid), dim3(256), 0, stream, slab, psplit, c_out, c_in, kt,
+                     taps, grad_w, accumulate);
+  return check_launch("wgrad_reduce");
+}
+
 struct WgradPlan {
-  int cfg;  // 0: (1,2,4) 3x3 narrow-n ; 1: (2,2,2) 3x3 ; 2: (1,1,8) 3x3 c_in 32 ; 3: (2,1,4) 1x1
+  int cfg;  // 0: (1,2,4) 3x3 narrow-n ; 1: (2,2,2) 3x3 ; 2: (1,1,8) 3x3 c_in 32 ; 3: (2,1,4) 1x1 ;
+            // 4: (1,1,8) 3x3 c_in 32 with ONE output frame (bf16): 4-row tiles, ring of two stages
   int NTN, NTC, DG, TH;
   int n_blocks, c_blocks, dt_blocks, psplit, t_out, ntiles;
   WgradLevels lv;
@@ -435,6 +473,11 @@ static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
     p->cfg = 1; p->NTN = 2; p->NTC = 2; p->DG = 2;
   }
   p->TH = f32 ? 4 : 8;
+  if (p->cfg == 2 && !f32 && p->t_out == 1 && d->kt > 1) {
+    // fast_conv3 (12 frames -> 1): nothing is re-used between stages, every stage needs DG new x frames.  With the
+    // two-tile look-ahead of the other configurations each stage waited a memory round trip for the other six.
+    p->cfg = 4; p->TH = 4;
+  }
   SFVOS_REQUIRE(d->pyr.n_levels >= 1 && d->pyr.n_levels <= SFVOS_MAX_LEVELS, "wgrad: n_levels out of range");
   SFVOS_REQUIRE(d->batch >= 1 && d->t_alloc >= 1 && d->t_offset > -(1 << 20) && d->t_offset < (1 << 20) &&
                 d->t_in < (1 << 20), "wgrad: bad x window");  // frames of the window outside [0, t_alloc) are zeros
@@ -491,10 +534,10 @@ static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
   return SFVOS_OK;
 }
 
-template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R>
+template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS = 2>
 static int launch_wgrad(const WgradArgs& a, long long grid, hipStream_t stream) {
-  typedef WgradCfg<DT, TAPS, NTN, NTC, DG, TH, R> C;
-  auto kern = wgrad_kernel<DT, TAPS, NTN, NTC, DG, TH, R>;
+  typedef WgradCfg<DT, TAPS, NTN, NTC, DG, TH, R, NXS> C;
+  auto kern = wgrad_kernel<DT, TAPS, NTN, NTC, DG, TH, R, NXS>;
   static LdsAttrOnce once;
   if (int rc = once.ensure((const void*)kern, C::LDS_BYTES, "wgrad")) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), C::LDS_BYTES, stream, a);
@@ -505,10 +548,25 @@ static int launch_wgrad(const WgradArgs& a, long long grid, hipStream_t stream) 
 
 using namespace sfvos;
 
+// The lateral k x 1 x 1 convs (32 -> 64 channels, bf16) have a kernel of their own (lateral_wgrad.hip: all kt taps per
+// workgroup, x and dy read once).  The workspace is sized for whichever of the two kernels needs more, so the generic one
+// stays available as the fallback.
+static bool lateral_wgrad_wanted(const sfvos_conv_desc* d) {
+#ifdef SFVOS_DIAG
+  if (getenv("SFVOS_NO_LATERAL_KERNEL")) return false;
+#endif
+  return d != nullptr && d->struct_size == (int)sizeof(sfvos_conv_desc);
+}
+
 extern "C" size_t sfvos_conv3d_wgrad_workspace_bytes(const sfvos_conv_desc* d) {
   WgradPlan p;
   if (make_wgrad_plan(d, &p) != SFVOS_OK) return 0;
-  return (size_t)p.psplit * d->c_out * d->c_in * d->kt * d->taps * sizeof(float);
+  size_t n = (size_t)p.psplit * d->c_out * d->c_in * d->kt * d->taps * sizeof(float);
+  if (lateral_wgrad_wanted(d)) {
+    const size_t m = lateral_wgrad_workspace_bytes(d);
+    if (m > n) n = m;
+  }
+  return n;
 }
 
 extern "C" int sfvos_conv3d_wgrad(const sfvos_conv_desc* d, const void* x, const void* dy, float* grad_w,
@@ -517,6 +575,10 @@ extern "C" int sfvos_conv3d_wgrad(const sfvos_conv_desc* d, const void* x, const
   int rc = make_wgrad_plan(d, &p);
   if (rc != SFVOS_OK) return rc;
   SFVOS_REQUIRE(x && dy && grad_w && workspace, "wgrad: null pointer");
+  if (lateral_wgrad_wanted(d)) {
+    rc = lateral_wgrad_try(d, x, dy, grad_w, accumulate, workspace, (hipStream_t)stream);
+    if (rc >= 0) return rc;
+  }
   WgradArgs a;
   a.x = (const char*)x; a.dy = (const char*)dy; a.slab = (float*)workspace;
   a.t_in = d->t_in; a.t_alloc = d->t_alloc; a.t_offset = d->t_offset; a.t_out = p.t_out; a.c_in = d->c_in;
@@ -535,13 +597,9 @@ extern "C" int sfvos_conv3d_wgrad(const sfvos_conv_desc* d, const void* x, const
     case 0: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 1, 2, 4, 8, 5>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 1, 2, 4, 4, 5>(a, grid, s); break;
     case 1: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 2, 2, 2, 8, 5>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 2, 2, 2, 4, 4>(a, grid, s); break;
     case 2: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 1, 1, 8, 8, 11>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 1, 1, 8, 4, 10>(a, grid, s); break;
+    case 4: rc = launch_wgrad<SFVOS_BF16, 9, 1, 1, 8, 4, 16, 8>(a, grid, s); break;
     default: rc = bf ? launch_wgrad<SFVOS_BF16, 1, 2, 1, 4, 8, 8>(a, grid, s) : launch_wgrad<SFVOS_F32, 1, 2, 1, 4, 4, 8>(a, grid, s); break;
   }
   if (rc != SFVOS_OK) return rc;
-  const long long total = (long long)d->c_out * d->c_in * d->kt * d->taps;
-  long long rgrid = ceil_div64(total, 256);
-  if (rgrid > 8192) rgrid = 8192;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)rgrid), dim3(256), 0, s, (const float*)workspace, p.psplit,
-                     d->c_out, d->c_in, d->kt, d->taps, grad_w, accumulate);
-  return check_launch("wgrad_reduce");
+  return launch_wgrad_reduce((const float*)workspace, p.psplit, d->c_out, d->c_in, d->kt, d->taps, grad_w, accumulate, s);
 }

@@ -65,7 +65,8 @@ typedef struct sfvos_levels {
 
 /* ABI revision: 100 = round 1; 200 = struct_size in sfvos_conv_desc, no `zeros` argument, sfvos_abi_sizes,
  * sfvos_add_inplace, sfvos_mse_loss / _grad, mask-head entry points; 201 = sfvos_bn_running argument of the BN-apply
- * calls, mask-branch training entry points, sfvos_pack_weights_batch, sfvos_pyramid_to_frames / sfvos_frames_to_pyramid. */
+ * calls, mask-branch training entry points, sfvos_pack_weights_batch, sfvos_pyramid_to_frames / sfvos_frames_to_pyramid;
+ * 300 (round 3) = sfvos_roi_levels / sfvos_roi_align / sfvos_roi_align_bwd (+ workspace query). */
 int sfvos_version(void);
 /* sizes[0..n) = sizeof(sfvos_conv_desc), sizeof(sfvos_pyramid), sizeof(sfvos_levels), sizeof(sfvos_mse_table),
  * sizeof(sfvos_bn_running), sizeof(sfvos_pack_item), sizeof(sfvos_planar_level) as THIS library was compiled; returns
@@ -363,6 +364,33 @@ int sfvos_mask_logits(const void* x, int dtype, const float* w, const float* bia
  * and truncated to integers, bilinear resize (align_corners = false) to the box, zero outside it. */
 int sfvos_paste_masks(const float* masks, const float* boxes, int n, int mask_size, int padding, int img_h, int img_w,
                       float* out, sfvos_stream_t stream);
+
+/* ---- MultiScaleRoIAlign in front of the mask branch (model.py:346: roi_heads' mask_roi_pool =
+ * MultiScaleRoIAlign(['0','1','2','3'], output_size 14, sampling_ratio 2) on the fused maps SlowFastLayers returns).
+ * rois: [n][5] fp32 (image index in the batch, x1, y1, x2, y2), image coordinates.  torchvision's arithmetic, restated
+ * (parity unpinned by the reference: torchvision is neither vendored nor installed). ---- */
+
+/* LevelMapper: levels[r] = clamp(floor(canonical_level + log2(sqrt(box area) / canonical_scale) + eps), k_min, k_max) - k_min
+ * (device int32 per RoI; torchvision: canonical_scale 224, canonical_level 4, eps 1e-6, k_min / k_max = -log2 of the first /
+ * last feature level's scale). */
+int sfvos_roi_levels(const float* rois, int n, int k_min, int k_max, float canonical_scale, float canonical_level,
+                     float eps, int* levels, sfvos_stream_t stream);
+
+/* Bytes of `workspace` for n RoIs (per-RoI tables of the separable bilinear parameters). */
+size_t sfvos_roi_align_workspace_bytes(int n);
+
+/* torchvision.ops.roi_align(feat, rois, pooled, spatial_scale, sampling_ratio, aligned = False) for the RoIs r with
+ * levels[r] == level (levels == NULL: all of them): feat [B][C][H][W] fp32 contiguous; out [n][C][pooled][pooled] fp32
+ * (rows of other levels are left untouched); sampling_ratio >= 1 and pooled * sampling_ratio <= 64. */
+int sfvos_roi_align(const float* feat, int B, int C, int H, int W, const float* rois, const int* levels, int level, int n,
+                    float spatial_scale, int pooled, int sampling_ratio, void* workspace, float* out,
+                    sfvos_stream_t stream);
+
+/* Its backward: dfeat [B][C][H][W] (=|+=) the gradient of the level's RoIs (dout [n][C][pooled][pooled]); a gather in a
+ * fixed order (deterministic; torchvision scatters with atomics).  n == 0 writes zeros (accumulate == 0). */
+int sfvos_roi_align_bwd(const float* dout, int B, int C, int H, int W, const float* rois, const int* levels, int level,
+                        int n, float spatial_scale, int pooled, int sampling_ratio, void* workspace, float* dfeat,
+                        int accumulate, sfvos_stream_t stream);
 
 /* ---- training side of the mask branch (the reference trains roi_heads: only backbone and RPN are frozen,
  * model.py:176-179; losses.backward() at model.py:369 runs through torchvision's maskrcnn_loss and these modules).

@@ -83,6 +83,12 @@ CONV_CASES = [
     (2, 21, [(9, 13), (3, 3), (1, 2)], 32, 64, 20, 1),   # t_out 2, kt 20, ragged tiles and idle waves
     (1, 8, [(16, 33)], 32, 64, 8, 1),                    # t_out 1
     (1, 22, [(24, 42), (12, 21), (6, 11)], 32, 64, 20, 1),  # t_out 3: the first lateral of cfg (2,1,4)
+    # weight images beyond 80 KB (bf16: one 12-wave workgroup per compute unit): kt 21 = conv_f2s2 of (4,64), kt 40 = all
+    # of the LDS, kt 41 = conv_f2s1 of (4,64): 40 taps in LDS + the last one in registers
+    (1, 22, [(12, 21), (5, 7)], 32, 64, 21, 1),
+    (2, 41, [(9, 13), (2, 2)], 32, 64, 40, 1),
+    (1, 43, [(24, 42), (6, 11)], 32, 64, 41, 1),
+    (1, 41, [(7, 9)], 32, 64, 41, 1),                    # t_out 1 with the register tap
 ]
 
 
@@ -228,6 +234,9 @@ def test_conv3d_window_beyond_the_buffer_reads_zero_frames(lib, prec, case):
                                   (1, 20, [(7, 9)], 32, 64, 20, 1),
                                   # kt = 41 (the (4,64) configuration): the weight image exceeds the LDS budget
                                   (1, 43, [(5, 9), (2, 2)], 32, 64, 41, 1),
+                                  # ... kt = 21 / 40: images of 84 / 160 KB (12-wave workgroups); kt 42: beyond (from L2)
+                                  (1, 22, [(12, 21), (3, 3)], 32, 64, 21, 1), (2, 41, [(6, 7)], 32, 64, 40, 1),
+                                  (1, 43, [(4, 9)], 32, 64, 42, 1),
                                   # fast_conv3's shape (all frames -> one): single-frame blocks, one temporal tap each
                                   (2, 12, [(9, 37), (4, 5)], 32, 32, 12, 9)])
 def test_conv3d_dgrad_and_accumulate(lib, prec, case):
@@ -380,6 +389,9 @@ def test_conv3d_wgrad_several_tiles_per_workgroup(lib, prec, case):
     th = 4 if prec == 'fp32' else 8
     ntiles = sum(B * -(-H // th) * -(-W // 16) for H, W in shapes)
     per = -(-ntiles // psplit)
+    if taps == 1 and prec == 'bf16':   # lateral_wgrad.hip: 16-position tiles, one slab per workgroup (its own test below)
+        ntiles = sum(B * -(-(H * W) // 16) for H, W in shapes)
+        per = -(-ntiles // min(256, max(1, ntiles // 8)))
     assert per >= 2, 'case does not sweep several tiles per workgroup (ntiles %d, split %d)' % (ntiles, psplit)
     ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
     gw = torch.full(ref.shape, 5.0, dtype=torch.float32, device='cuda')
@@ -387,6 +399,54 @@ def test_conv3d_wgrad_several_tiles_per_workgroup(lib, prec, case):
     e = relmax(gw.cpu(), ref)
     print('wgrad %s %s: %d tiles, split %d, %d tiles per workgroup, max err / scale %.2e' % (case, prec, ntiles, psplit, per, e))
     assert e < TOL[prec]
+
+
+# The lateral convs' own weight-gradient kernel (lateral_wgrad.hip, bf16, 32 -> 64 channels, t_out <= 3, kt <= 48): all taps
+# per workgroup, LDS ring with counted waits.  Cases: every t_out, taps per wave 1..6 (kt 1..48) incl. the benchmark's
+# (20, 3) / (11, 2) and configuration 4's (41, 3) / (21, 2); level sizes that are not multiples of the 16-position tile;
+# two clips; pitches wider than the channel count; a frame window inside a longer buffer; more tiles than workgroups
+# (several stages per workgroup, ring wrap) and fewer (workgroups with a single stage).
+LAT_WGRAD_CASES = [
+    # B  t_alloc t_off T   shapes                          kt
+    (1, 22, 0, 22, [(96, 168), (24, 42), (12, 21)], 20),   # t_out 3: conv_f2s1 of (4,32), 20k positions
+    (1, 12, 0, 12, [(48, 84), (5, 9)], 11),                # t_out 2: conv_f2s2 of (4,32)
+    (1, 43, 0, 43, [(24, 42), (12, 21)], 41),              # t_out 3: conv_f2s1 of (4,64): 6 taps per wave, ring of 3
+    (1, 22, 0, 22, [(24, 42)], 21),                        # t_out 2: conv_f2s2 of (4,64)
+    (2, 9, 2, 6, [(5, 21), (2, 3), (1, 1)], 4),            # window [2, 8) of 9 frames, two clips, tiny ragged levels
+    (1, 1, 0, 1, [(7, 9)], 1),                             # kt 1, t_out 1 (equal pathway sizes)
+    (2, 50, 1, 48, [(3, 11)], 48),                         # the largest kt the kernel takes, t_out 1
+    (1, 7, 0, 7, [(13, 17)], 5),                           # t_out 3, kt 5
+]
+
+
+@pytest.mark.parametrize('case', LAT_WGRAD_CASES)
+def test_lateral_wgrad_kernel(lib, case):
+    B, Ta, off, T, shapes, kt = case
+    g = torch.Generator().manual_seed(19)
+    w = torch.zeros(64, 32, kt, 1, 1, requires_grad=True)
+    t_out = T - kt + 1
+    xs = [torch.randn(B, 32, Ta, H, W, generator=g).bfloat16().float() for (H, W) in shapes]
+    dys = [torch.randn(B, 64, t_out, H, W, generator=g).bfloat16().float() for (H, W) in shapes]
+    for x, dy in zip(xs, dys):
+        F.conv3d(x[:, :, off:off + T], w, None).backward(dy)
+    ref = w.grad
+    ld_x, ld_y = 40, 96
+    xd, dyd = to_pyr(xs, 'bf16', ld_x), to_pyr(dys, 'bf16', ld_y)
+    d, _ = make_desc(lib, 'bf16', B, T, shapes, 32, 64, kt, 1, 0, ld_x, ld_y, t_alloc=Ta, t_offset=off)
+    nbytes = lib.load().sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
+    assert nbytes > 0
+    ws = torch.full((nbytes // 4,), float('nan'), dtype=torch.float32, device='cuda')   # stale slabs must not leak
+    gw = torch.full(ref.shape, 5.0, dtype=torch.float32, device='cuda')
+    lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(xd), P(dyd), P(gw), 0, P(ws), S())
+    e = relmax(gw.cpu(), ref)
+    print('lateral wgrad %s: max err / scale %.2e' % (case, e))
+    assert e < TOL['bf16']
+    first = gw.clone()
+    lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(xd), P(dyd), P(gw), 1, P(ws), S())
+    assert relmax(gw.cpu(), 2 * ref) < 2 * TOL['bf16']
+    gw2 = torch.empty_like(gw)
+    lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(xd), P(dyd), P(gw2), 0, P(ws), S())
+    assert torch.equal(first, gw2), 'the weight gradient must be bit-identical from run to run'
 
 
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])

@@ -228,8 +228,9 @@ def test_mask_branch_fused_sgd_trajectory_matches_the_oracle(precision):
     model.py:176-179).  FusedSGD rewrites the parameters through raw pointers, so the branch's packed weight images
     (3x3 fwd / dgrad, deconv fwd / dgrad) must follow _lib.weight_epoch(): four optimiser steps of MaskBranch under
     the package's FusedSGD against the oracle under torch.optim.SGD -- losses of every step (a stale image shows from
-    step 2 on), logits after the last step, and the parameters themselves.  lr is raised to 0.05 so that one step
-    moves the logits far beyond the tolerance."""
+    step 2 on), logits after the last step, and the parameters themselves.  lr is raised to 0.02 so that one step
+    moves the loss far beyond the tolerance (a stale image leaves the step-2 loss at its step-1 value); the trajectory
+    itself amplifies the ReLU-mask flips of two correct implementations, hence 1e-2 on later losses in fp32."""
     from sfvos_amd import FusedSGD, maskrcnn_loss
     m, o = make(precision)
     N = 6
@@ -239,8 +240,8 @@ def test_mask_branch_fused_sgd_trajectory_matches_the_oracle(precision):
     targets = (torch.rand(N, 28, 28, generator=g) > 0.5).float()
     if precision == 'bf16':
         x = x.bfloat16().float()
-    opt = FusedSGD(m.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
-    ropt = torch.optim.SGD(o.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    opt = FusedSGD(m.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+    ropt = torch.optim.SGD(o.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
     xg = x.to(DEV)
     losses, rlosses = [], []
     for step in range(4):
@@ -256,10 +257,10 @@ def test_mask_branch_fused_sgd_trajectory_matches_the_oracle(precision):
         rlosses.append(float(rl.detach()))
     with torch.no_grad():
         got, ref = m(xg).cpu(), o(x)
-    tol_l, tol_o = (2e-4, 2e-3) if precision == 'fp32' else (5e-2, 0.15)
+    tol_l, tol_o = (1e-2, 5e-2) if precision == 'fp32' else (5e-2, 0.15)
     print('mask branch %s FusedSGD trajectory: losses %s vs oracle %s; logits after 4 steps %.2e'
           % (precision, ['%.5f' % v for v in losses], ['%.5f' % v for v in rlosses], relmax(got, ref)))
-    assert abs(rlosses[0] - rlosses[-1]) > 20 * tol_l * abs(rlosses[0]), 'the trajectory must move'
+    assert min(abs(a - b) for a, b in zip(rlosses, rlosses[1:])) > 0.1 * abs(rlosses[0]), 'every step must move the loss'
     for a, b in zip(losses, rlosses):
         assert abs(a - b) <= tol_l * abs(b), (losses, rlosses)
     assert relmax(got, ref) < tol_o

@@ -154,6 +154,13 @@ if which == 'wall':
     wgrad('f3 32->32 k12', 12, 32, 32, 12, 9, reps=reps)
     wgrad('l1 32->64 k20', 22, 32, 64, 20, 1, reps=reps)
     wgrad('l2 32->64 k11', 12, 32, 64, 11, 1, reps=reps)
+if which == 'wlat':   # the HBM-bound weight gradients: laterals and fast_conv3 of (4,32) and (4,64)
+    wgrad('l1 32->64 k20', 22, 32, 64, 20, 1, reps=reps)
+    wgrad('l2 32->64 k11', 12, 32, 64, 11, 1, reps=reps)
+    wgrad('f3 32->32 k12', 12, 32, 32, 12, 9, reps=reps)
+    wgrad('C4 l1 32->64 k41', 43, 32, 64, 41, 1, reps=reps)
+    wgrad('C4 l2 32->64 k21', 22, 32, 64, 21, 1, reps=reps)
+    wgrad('C4 f3 32->32 k22', 22, 32, 32, 22, 9, reps=reps)
 if which == 'f3':
     conv('f3 32->32 k12', 12, 32, 32, 12, 9, reps=reps)
     conv('dgrad f3 32->32 k12', 1, 32, 32, 12, 9, pad_t=11, reps=reps, acc=1)
