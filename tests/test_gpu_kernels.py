@@ -89,6 +89,11 @@ CONV_CASES = [
     (2, 41, [(9, 13), (2, 2)], 32, 64, 40, 1),
     (1, 43, [(24, 42), (6, 11)], 32, 64, 41, 1),
     (1, 41, [(7, 9)], 32, 64, 41, 1),                    # t_out 1 with the register tap
+    # frame-split kernel, bf16: levels whose width leaves <= 16 px behind the 32-px tile columns get a column of TALL
+    # (16 rows x 16 px) tiles: 42 = 32 + 10, 48 = 32 + 16 (17 rows: two tall tiles, the second almost empty), 21 stays
+    # a padded 32-px tile, 10 and 5 are tall tiles only; 4-, 2- and 1-frame blocks (t_out 7 = 4 + 2 + 1)
+    (1, 9, [(24, 42), (17, 48), (12, 21)], 256, 32, 3, 9),
+    (2, 8, [(40, 10), (3, 5)], 32, 32, 2, 9),
 ]
 
 

@@ -298,7 +298,7 @@ FULL_GATES = {
     # (4,64) on 21 420 positions: a flipped ReLU mask weighs 4x more than at 85 932 -- 70 flips move the layer-1/2
     # gradients by 1.3e-2 rel-L2 (single entries of slow_conv2.weight by 0.13 of the scale); with the SAME masks on both
     # sides they agree at 5e-6 (test_full_size_fp32_relu_mask_flips_explain_the_gradient_error[c4])
-    ('c4', 'fp32'): dict(out=2e-5, loss=1e-5, g3=(1e-4, 1e-4), g12=(3e-2, 0.3), stat=1e-4, param=1e-5),
+    ('c4', 'fp32'): dict(out=2e-5, loss=1e-5, g3=(1e-4, 1e-4), g12=(3e-2, 0.3), stat=1e-4, param=1e-4),
     ('c4', 'bf16'): dict(out=5e-2, loss=2e-2, g3=(2e-2, 2e-2), g12=(0.15, 0.3), stat=2e-2, param=1e-3),
 }
 
