@@ -507,7 +507,12 @@ struct FsCfg {
 // cycles per FLOP as 32x32x16, but the chip holds a higher clock on this shape under load.
 // (TAG: a second kernel that instantiates the same body needs its own specialisation -- host compilation rejects a
 // second reference to one specialisation of this device-only template)
-template <int DT, int TT, int RS, int CIN, bool M16, int TAG = 0>
+// STAT (input-stationary sweep; TT = 1, bf16): the data gradient of a conv with ONE output frame (fast_conv3: its input
+// gradient has kt frames, each of which meets exactly one temporal tap of the single dy frame).  As single-frame blocks
+// that is kt workgroups per pixel tile, each copying the same dy halo tile and one weight slice for one stage of MFMAs.
+// Here ONE workgroup per pixel tile copies the dy tile once (ring slot 1; slot 0 is the epilogue's scratch), then walks
+// the output frames: weight slice of the frame's tap (double-buffered), one stage, store the frame.
+template <int DT, int TT, int RS, int CIN, bool M16, int TAG = 0, bool STAT = false>
 __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const ConvArgs::Part& pt) {
   typedef FsCfg<DT, TT, RS> C;
   // F8 (e4m3 operands, SFVOS_FP8): v_mfma_scale_f32_32x32x64_f8f6f4 -- one instruction consumes a pixel's whole
@@ -737,12 +742,88 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
       __builtin_amdgcn_sched_barrier(0);
       if (t % PSTRIDE == 0 && t / PSTRIDE < NPIECE) piece(d, t / PSTRIDE);
       if (t == 1) {
-        if (s + 1 < S) prep_stage(dn, nx, s + 1);
+        if constexpr (STAT) dn.do_x = dn.do_w = false;
+        else if (s + 1 < S) prep_stage(dn, nx, s + 1);
         else dn.do_x = dn.do_w = false;
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
+
+  float s1 = 0.f, s2 = 0.f;  // per-lane partial statistics of channel r (32x32) / channels p16, 16+p16 (16x16)
+  float s1b = 0.f, s2b = 0.f;
+  T* yclip = (T*)a.y + (a.lv.ypos[lvl] + b * a.lv.ybs[lvl]) * a.ld_y;
+  const long long yfs = a.lv.yfs[lvl];
+  // ---- epilogue, 16x16 tiles (bf16): the wave's 16 pixel columns x 32 channels of each row go through a per-wave
+  // f32 scratch (the first 17 KB of LDS) and leave as one 16-byte chunk per lane (lane -> pixel lane/4, channels
+  // 8*(lane%4)..+7)
+  auto store_m16 = [&](const int to) {
+    float* scr = (float*)smem + wv * (16 * 33);
+    const float bias0 = a.bias ? a.bias[p16] : 0.f, bias1 = a.bias ? a.bias[16 + p16] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int h = h0 + rs * MT + i;
+      if (h >= H) continue;  // wave-uniform
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int px = 4 * g16 + e;
+        float v0 = acc16[i][0][e] + bias0, v1 = acc16[i][1][e] + bias1;
+        if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+        scr[px * 33 + p16] = v0;
+        scr[px * 33 + 16 + p16] = v1;
+        if (w0 + kh * 16 + px < W) { s1 += v0; s2 += v0 * v0; s1b += v1; s2b += v1 * v1; }
+      }
+      const int px = lane >> 2, ch = (lane & 3) * 8;
+      float f[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) f[u] = scr[px * 33 + ch + u];
+      if (w0 + kh * 16 + px < W) {
+        T* dst = yclip + (to * yfs + (long long)h * W + w0 + kh * 16 + px) * a.ld_y + ch;
+        if (a.accumulate) {
+          const u32x4 old = *(const u32x4*)dst;
+          T oldv[8];
+          __builtin_memcpy(oldv, &old, 16);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) f[u] += Elt<YDT>::to_f32(oldv[u]);
+        }
+        T outv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) outv[u] = Elt<YDT>::from_f32(f[u]);
+        u32x4 o;
+        __builtin_memcpy(&o, outv, 16);
+        *(u32x4*)dst = o;
+      }
+    }
+  };
+
+  if constexpr (STAT) {
+    static_assert(TT == 1 && M16, "the input-stationary sweep is a single-frame bf16 body");
+    // the window's only real frame (t = 0 = tb0 - pad_t + i for i = pad_t: tb0 is 0 here) -> ring slot 1, once
+    {
+      Dma f; f.do_w = false;
+      prep_frame(f, 0, a.pad_t, 1);
+      issue_all(f);
+      Dma w; w.do_x = false;
+      prep_w(w, 0, a.pad_t - pt.t_first, 0);
+      issue_all(w);
+    }
+    int k = 0;
+    for (int to = pt.t_first; to < pt.t_end; ++to, ++k) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();   // this frame's weight slice (and, the first time, the dy tile) landed; the other buffer is free
+      Dma dw; dw.do_x = dw.do_w = false;
+      if (to + 1 < pt.t_end) prep_w(dw, 0, a.pad_t - (to + 1), k + 1);   // output frame t meets tap pad_t - t only
+      const Stage cur{0, a.pad_t - to, 1};
+      Dma dn;
+      compute(k, cur, dw, dn, cur);
+      store_m16(to);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc16[i][0][e] = acc16[i][1][e] = 0.f;
+    }
+    return;   // (no statistics rows: a data gradient has none)
+  }
 
   // ---- main loop ----------------------------------------------------------------------------------------
   int s = 0;
@@ -791,53 +872,10 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
     a.stamps[8 * 128 * 4 + wv * 4 + 3] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
-  float s1 = 0.f, s2 = 0.f;  // per-lane partial statistics of channel r (32x32) / channels p16, 16+p16 (16x16)
-  float s1b = 0.f, s2b = 0.f;
-  T* yclip = (T*)a.y + (a.lv.ypos[lvl] + b * a.lv.ybs[lvl]) * a.ld_y;
-  const long long yfs = a.lv.yfs[lvl];
   const int to = tb0 + jf;
   __syncthreads();  // ring / weight buffers are dead
   if constexpr (M16) {
-    // ---- epilogue, 16x16 tiles: the wave's 16 pixel columns x 32 channels of each row go through a per-wave
-    // f32 scratch and leave as one 16-byte chunk per lane (lane -> pixel lane/4, channels 8*(lane%4)..+7)
-    float* scr = (float*)smem + wv * (16 * 33);
-    const float bias0 = a.bias ? a.bias[p16] : 0.f, bias1 = a.bias ? a.bias[16 + p16] : 0.f;
-    if (to < pt.t_end) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int h = h0 + rs * MT + i;
-        if (h >= H) continue;  // wave-uniform
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int px = 4 * g16 + e;
-          float v0 = acc16[i][0][e] + bias0, v1 = acc16[i][1][e] + bias1;
-          if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-          scr[px * 33 + p16] = v0;
-          scr[px * 33 + 16 + p16] = v1;
-          if (w0 + kh * 16 + px < W) { s1 += v0; s2 += v0 * v0; s1b += v1; s2b += v1 * v1; }
-        }
-        const int px = lane >> 2, ch = (lane & 3) * 8;
-        float f[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) f[u] = scr[px * 33 + ch + u];
-        if (w0 + kh * 16 + px < W) {
-          T* dst = yclip + (to * yfs + (long long)h * W + w0 + kh * 16 + px) * a.ld_y + ch;
-          if (a.accumulate) {
-            const u32x4 old = *(const u32x4*)dst;
-            T oldv[8];
-            __builtin_memcpy(oldv, &old, 16);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) f[u] += Elt<DT>::to_f32(oldv[u]);
-          }
-          T outv[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) outv[u] = Elt<DT>::from_f32(f[u]);
-          u32x4 o;
-          __builtin_memcpy(&o, outv, 16);
-          *(u32x4*)dst = o;
-        }
-      }
-    }
+    if (to < pt.t_end) store_m16(to);
   } else {
 // ---- K-half exchange: each partner hands the other the tiles it will not finish ----------------------
     f32x16 fin[HM];
@@ -988,8 +1026,18 @@ __global__ __launch_bounds__(512, 4) void conv3d_fs1_kernel(ConvArgs a) {
   fs_body<DT, 1, 4, CIN, M16, 1>(a, wg, a.part[2]);
 }
 
+// The input-stationary sweep (fs_body STAT): one workgroup per pixel tile walks all output frames of a data gradient whose
+// input has a single frame.  80 KB of LDS, two workgroups per CU.
+template <int DT, int CIN = 0>
+__global__ __launch_bounds__(512, 4) void conv3d_fs1s_kernel(ConvArgs a) {
+  constexpr bool M16 = DT == SFVOS_BF16;
+  const int wg = blockIdx.x;
+  fs_body<DT, 1, 4, CIN, M16, 2, true>(a, wg, a.part[2]);
+}
+
 // ---- host-side planning ----------------------------------------------------------------------------
 struct ConvPlan {
+  int stat;    // family 3: input-stationary sweep over the output frames (conv3d_fs1s_kernel)
   int family;  // 0 narrow 1x1 (c_out <= 32), 1 mid (c_out == 64, 1x1), 2 wide, 3 frame-split (c_out <= 32, 3x3),
                // 4 lateral forward (lateral.hip: its own kernel, one statistics row per workgroup)
   int TT, MT, NT, TH, BN;
@@ -1075,6 +1123,7 @@ static void split_frames_balanced(int t_out, long long units, ConvPlan* p) {
 
 static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
   SFVOS_REQUIRE(d != nullptr, "conv: null desc");
+  p->stat = 0;
   SFVOS_REQUIRE(d->struct_size == (int)sizeof(sfvos_conv_desc),
                 "conv: sfvos_conv_desc.struct_size is %d, this library's struct has %d bytes (stale binding?)",
                 d->struct_size, (int)sizeof(sfvos_conv_desc));
@@ -1124,11 +1173,13 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
     p->family = 3; split_frames_balanced(p->t_out, units, p); p->NT = 1; p->TH = 8; p->BN = 32;
     if (d->t_in == 1 && d->pad_t == d->kt - 1 && d->kt > 1 && d->dtype == SFVOS_BF16) {
       // data gradient of a conv with ONE output frame (fast_conv3): every frame of dx meets exactly one temporal tap, so
-      // a multi-frame block multiplies TT taps x TT frames of which TT are real.  Single-frame blocks multiply none in
-      // vain and run two per CU (conv3d_fs1_kernel).
-      p->l_blocks[0] = p->l_blocks[1] = 0; p->l_blocks[2] = p->t_out;
+      // a multi-frame block multiplies TT taps x TT frames of which TT are real.  One workgroup per pixel tile keeps
+      // the dy tile and walks the t_out frames, one weight slice and one stage each (conv3d_fs1s_kernel; single-frame
+      // blocks copied the same dy tile t_out times).
+      p->stat = 1;
+      p->l_blocks[0] = p->l_blocks[1] = 0; p->l_blocks[2] = 1;
       p->l_first[0] = p->l_first[1] = p->l_first[2] = 0;
-      p->t_blocks = p->t_out;
+      p->t_blocks = 1;
     }
   } else if (d->c_out <= 32) {
     p->family = 0; split_frames(p->t_out, 4, p); p->MT = 1; p->NT = 1; p->TH = 8; p->BN = 32;
@@ -1216,6 +1267,21 @@ static int launch(const ConvArgs& a, long long grid, hipStream_t stream) {
   if (int rc = once.ensure((const void*)kern, C::LDS_BYTES, "conv")) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NTHREADS), C::LDS_BYTES, stream, a);
   return check_launch("conv3d");
+}
+
+template <int DT, int CIN = 0>
+static int launch_fs1s(const ConvArgs& a, long long grid, hipStream_t stream) {
+  if constexpr (DT == SFVOS_BF16) {
+    constexpr int LDS1 = FsCfg<DT, 1, 4>::LDS_BYTES;
+    auto kern = conv3d_fs1s_kernel<DT, CIN>;
+    static LdsAttrOnce once;
+    if (int rc = once.ensure((const void*)kern, LDS1, "conv")) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), LDS1, stream, a);
+    return check_launch("conv3d_fs1s");
+  } else {
+    set_error("conv: the input-stationary sweep is a bf16 kernel");
+    return SFVOS_E_ARG;
+  }
 }
 
 template <int DT, int CIN = 0>
@@ -1324,6 +1390,7 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
     for (int c = 0; c < 3; ++c) {
       ConvArgs::Part& pt = a.part[c];
       pt.t_blocks = p.l_blocks[c]; pt.t_first = p.l_first[c]; pt.t_end = pt.t_first + p.l_tt[c] * pt.t_blocks;
+      if (p.stat && c == 2) pt.t_end = p.t_out;   // the one "block" of the stationary sweep covers every output frame
       pt.tb_offset = tb_offset;
       tb_offset += pt.t_blocks;
       const long long wgs = (long long)p.lv.wg_begin[SFVOS_MAX_LEVELS] * pt.t_blocks;
@@ -1332,6 +1399,7 @@ extern "C" int sfvos_conv3d(const sfvos_conv_desc* d, const void* x, const void*
       grid += wgs;
     }
     SFVOS_REQUIRE(grid > 0 && grid < (1ll << 31), "conv: grid %lld out of range", grid);
+    if (p.stat) return launch_fs1s<SFVOS_BF16>(a, grid, s);   // (make_plan sets it for bf16 only)
     if (d->dtype == SFVOS_BF16)
       return d->c_in == 256 ? launch_fs<SFVOS_BF16, 256>(a, grid, s) : launch_fs<SFVOS_BF16>(a, grid, s);
     if (d->dtype == SFVOS_FP8) return d->c_in == 256 ? launch_fs<SFVOS_FP8, 256>(a, grid, s) : launch_fs<SFVOS_FP8>(a, grid, s);
