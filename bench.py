@@ -142,7 +142,7 @@ def pmc_traffic(path, kernel):
         return None
 
 
-PMC_SUMMARY = 'r02_pmc_summary.json'   # the committed counter summary `roofline.traffic` is read from
+PMC_SUMMARY = 'r03_pmc_summary.json'   # the committed counter summary `roofline.traffic` is read from
 
 
 def make_step(model, opt, bucket, loss_fn, forward):
@@ -264,6 +264,20 @@ def main():
         return main_fp8(args)
     rank, world, local = init_distributed(force=args.force_dist)
     dist_on = world > 1 or args.force_dist
+    if dist_on:
+        # RCCL prints a version banner on stdout when its communicator is created (lazily, at the first collective):
+        # create it now with stdout pointed at stderr, so that stdout carries nothing but rank 0's ONE JSON line
+        torch.cuda.set_device((local % torch.cuda.device_count()) if world > 1 else 0)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     if world != args.gpus and rank == 0:
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
     dev = torch.device('cuda', (local % torch.cuda.device_count()) if world > 1 else 0)
