@@ -178,3 +178,62 @@ def test_mask_branch_surface_matches_torchvision_names():
     for k in sm:
         assert sm[k].shape == so[k].shape
     m.load_state_dict(so, strict=True)
+
+
+def test_grad_bucket_force_runs_the_collectives_on_one_rank():
+    """GradBucket(force=True) with a world-size-1 process group (here gloo on CPU; tests/test_gpu_rccl.py does the same
+    with nccl = RCCL on the GPU box): the bucket is active, every reported range becomes a collective, the result of an
+    all-reduce over one rank is the input, and without `force` one rank stays a no-op."""
+    import torch.distributed as dist
+    from sfvos_amd import GradBucket, init_distributed
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    old = {k: os.environ.get(k) for k in ('MASTER_ADDR', 'MASTER_PORT', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    try:
+        assert init_distributed(backend='gloo') == (0, 1, 0) and not dist.is_initialized()   # one rank, not forced: nothing
+        assert init_distributed(backend='gloo', force=True) == (0, 1, 0) and dist.is_initialized()
+        flat = torch.arange(4096, dtype=torch.float32)
+        idle = GradBucket(flat.clone())
+        assert not idle.active
+        idle.arm(); assert not idle.armed
+        idle.all_reduce(); assert idle.collectives == 0
+        b = GradBucket(flat, force=True)
+        assert b.active and b.world == 1
+        b.set_buckets([(0, 1000), (1000, 4096)])
+        b.arm()
+        b.segment_ready(1000, 3000); assert b.collectives == 0      # bucket (1000, 4096) incomplete
+        b.segment_ready(3000, 4096); assert b.collectives == 1
+        b.segment_ready(0, 1000); assert b.collectives == 2
+        b.finish()
+        assert b.collectives == 2 and torch.equal(flat, torch.arange(4096, dtype=torch.float32))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_packed_clip_layouts_and_roi_align_host_logic():
+    from sfvos_amd import MultiScaleRoIAlign, PackedClip, roi_align
+    M = 2 * (3 * 4 + 2 * 2)
+    assert PackedClip(torch.zeros(M, 256, dtype=torch.bfloat16), [(3, 4), (2, 2)], 1, 2).layout == 'ndhwc'
+    assert PackedClip(torch.zeros(8, M, 32, dtype=torch.bfloat16), [(3, 4), (2, 2)], 1, 2).layout == 'grouped'
+    c8 = PackedClip(torch.zeros(4, M, 64, dtype=torch.uint8), [(3, 4), (2, 2)], 1, 2)
+    assert c8.layout == 'grouped8' and c8.channels == 256 and c8.window == 2
+    with pytest.raises(ValueError):
+        PackedClip(torch.zeros(4, M, 64, dtype=torch.bfloat16), [(3, 4), (2, 2)], 1, 2)   # 64-wide groups are e4m3 bytes
+    with pytest.raises(ValueError):
+        PackedClip(torch.zeros(M + 1, 256), [(3, 4), (2, 2)], 1, 2)
+    # scales as torchvision infers them: the power of two nearest to feature size / image size
+    pool = MultiScaleRoIAlign(['0', '1', '2', '3'], 14, 2)
+    feats = [torch.zeros(1, 8, h, w) for h, w in ((192, 336), (96, 168), (48, 84), (24, 42))]
+    pool.setup_scales(feats, [(749, 1333)])
+    assert pool.scales == [0.25, 0.125, 0.0625, 0.03125] and (pool.k_min, pool.k_max) == (2, 5)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        roi_align(torch.zeros(1, 8, 4, 4), torch.zeros(1, 5), 7, 1.0, 2)
+    with pytest.raises(NotImplementedError):
+        MultiScaleRoIAlign(['0'], 14, 0)
