@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libsfvos.so')
-SOURCES = ['runtime.hip', 'elementwise.hip', 'batchnorm.hip', 'conv3d.hip', 'wgrad.hip', 'lateral.hip', 'lateral_wgrad.hip', 'maskhead.hip', 'roialign.hip']
+SOURCES = ['runtime.hip', 'elementwise.hip', 'batchnorm.hip', 'conv3d.hip', 'wgrad.hip', 'lateral.hip', 'lateral_wgrad.hip', 'wgrad_t1.hip', 'maskhead.hip', 'roialign.hip']
 HEADERS = ['common.h', 'elt_util.h']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 

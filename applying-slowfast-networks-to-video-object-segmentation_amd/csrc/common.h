@@ -134,6 +134,10 @@ size_t lateral_wgrad_workspace_bytes(const sfvos_conv_desc* d);
 int lateral_wgrad_try(const sfvos_conv_desc* d, const void* x, const void* dy, float* grad_w, int accumulate,
                       void* workspace, hipStream_t stream);
 // wgrad.hip: grad_w[n][c][dt][tap] (=|+=) sum over the psplit slabs [n][dt][tap][c], fixed order
+// wgrad_t1.hip: weight gradient of a kt x 3 x 3 conv 32 -> 32 with one output frame (fast_conv3); -1 / 0 = shape not covered
+size_t wgrad_t1_workspace_bytes(const sfvos_conv_desc* d);
+int wgrad_t1_try(const sfvos_conv_desc* d, const void* x, const void* dy, float* grad_w, int accumulate, void* workspace,
+                 hipStream_t stream);
 int launch_wgrad_reduce(const float* slab, int psplit, int c_out, int c_in, int kt, int taps, float* grad_w,
                         int accumulate, hipStream_t stream);
 

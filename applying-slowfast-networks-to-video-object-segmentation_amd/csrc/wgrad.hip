@@ -549,7 +549,7 @@ static int launch_wgrad(const WgradArgs& a, long long grid, hipStream_t stream) 
 using namespace sfvos;
 
 // The lateral k x 1 x 1 convs (32 -> 64 channels, bf16) have a kernel of their own (lateral_wgrad.hip: all kt taps per
-// workgroup, x and dy read once).  The workspace is sized for whichever of the two kernels needs more, so the generic one
+// workgroup, x and dy read once), and so has the kt x 3 x 3 conv 32 -> 32 with one output frame (wgrad_t1.hip).  The workspace is sized for whichever of the two kernels needs more, so the generic one
 // stays available as the fallback.
 static bool lateral_wgrad_wanted(const sfvos_conv_desc* d) {
 #ifdef SFVOS_DIAG
@@ -563,7 +563,9 @@ extern "C" size_t sfvos_conv3d_wgrad_workspace_bytes(const sfvos_conv_desc* d) {
   if (make_wgrad_plan(d, &p) != SFVOS_OK) return 0;
   size_t n = (size_t)p.psplit * d->c_out * d->c_in * d->kt * d->taps * sizeof(float);
   if (lateral_wgrad_wanted(d)) {
-    const size_t m = lateral_wgrad_workspace_bytes(d);
+    size_t m = lateral_wgrad_workspace_bytes(d);
+    if (m > n) n = m;
+    m = wgrad_t1_workspace_bytes(d);
     if (m > n) n = m;
   }
   return n;
@@ -578,6 +580,14 @@ extern "C" int sfvos_conv3d_wgrad(const sfvos_conv_desc* d, const void* x, const
   if (lateral_wgrad_wanted(d)) {
     rc = lateral_wgrad_try(d, x, dy, grad_w, accumulate, workspace, (hipStream_t)stream);
     if (rc >= 0) return rc;
+    bool t1_ok = true;
+#ifdef SFVOS_DIAG
+    t1_ok = !getenv("SFVOS_NO_T1_KERNEL");
+#endif
+    if (t1_ok) {
+      rc = wgrad_t1_try(d, x, dy, grad_w, accumulate, workspace, (hipStream_t)stream);   // fast_conv3: one tap per workgroup
+      if (rc >= 0) return rc;
+    }
   }
   WgradArgs a;
   a.x = (const char*)x; a.dy = (const char*)dy; a.slab = (float*)workspace;

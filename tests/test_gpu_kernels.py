@@ -454,6 +454,50 @@ def test_lateral_wgrad_kernel(lib, case):
     assert torch.equal(first, gw2), 'the weight gradient must be bit-identical from run to run'
 
 
+# The weight gradient of a kt x 3 x 3 conv 32 -> 32 with ONE output frame (wgrad_t1.hip, bf16: fast_conv3): one temporal
+# tap per workgroup, the eight waves split a 16 x 16 tile's rows and are summed through LDS.  Cases: the benchmark's kt = 12
+# and configuration 4's kt = 22; level sizes that are not multiples of the tile (ragged right / bottom edges, a level smaller
+# than one tile); two clips; pitches wider than the channel count; a frame window inside a longer buffer; more tiles than
+# shares (ring wrap, level and clip boundaries inside a share) and fewer.
+T1_WGRAD_CASES = [
+    # B  t_alloc t_off shapes                             kt
+    (1, 12, 0, [(96, 168), (24, 42), (12, 21)], 12),      # fast_conv3 of (4,32): 66 + 6 + 2 tiles over 21 shares
+    (1, 22, 0, [(48, 84), (12, 21)], 22),                 # fast_conv3 of (4,64)
+    (2, 7, 2, [(17, 33), (5, 3), (1, 1)], 4),             # window [2, 6) of 7 frames, two clips, ragged and tiny levels
+    (1, 2, 0, [(16, 16)], 2),                             # one tile, kt 2
+    (2, 3, 0, [(40, 50)], 3),                             # 12 tiles per clip, two clips
+]
+
+
+@pytest.mark.parametrize('case', T1_WGRAD_CASES)
+def test_one_output_frame_wgrad_kernel(lib, case):
+    B, Ta, off, shapes, kt = case
+    g = torch.Generator().manual_seed(23)
+    w = torch.zeros(32, 32, kt, 3, 3, requires_grad=True)
+    xs = [torch.randn(B, 32, Ta, H, W, generator=g).bfloat16().float() for (H, W) in shapes]
+    dys = [torch.randn(B, 32, 1, H, W, generator=g).bfloat16().float() for (H, W) in shapes]
+    for x, dy in zip(xs, dys):
+        F.conv3d(x[:, :, off:off + kt], w, None, padding=(0, 1, 1)).backward(dy)
+    ref = w.grad
+    ld_x, ld_y = 40, 64
+    xd, dyd = to_pyr(xs, 'bf16', ld_x), to_pyr(dys, 'bf16', ld_y)
+    d, _ = make_desc(lib, 'bf16', B, kt, shapes, 32, 32, kt, 9, 0, ld_x, ld_y, t_alloc=Ta, t_offset=off)
+    nbytes = lib.load().sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
+    assert nbytes > 0
+    ws = torch.full((nbytes // 4,), float('nan'), dtype=torch.float32, device='cuda')   # stale slabs must not leak
+    gw = torch.full(ref.shape, 5.0, dtype=torch.float32, device='cuda')
+    lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(xd), P(dyd), P(gw), 0, P(ws), S())
+    e = relmax(gw.cpu(), ref)
+    print('one-output-frame wgrad %s: max err / scale %.2e' % (case, e))
+    assert e < TOL['bf16']
+    first = gw.clone()
+    lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(xd), P(dyd), P(gw), 1, P(ws), S())
+    assert relmax(gw.cpu(), 2 * ref) < 2 * TOL['bf16']
+    gw2 = torch.empty_like(gw)
+    lib.call('sfvos_conv3d_wgrad', ctypes.byref(d), P(xd), P(dyd), P(gw2), 0, P(ws), S())
+    assert torch.equal(first, gw2), 'the weight gradient must be bit-identical from run to run'
+
+
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 def test_add_inplace_and_mse_loss(lib, prec):
     """sfvos_add_inplace (gradient fan-in of the slow window) and the stand-in loss (value + gradient) against torch."""

@@ -1,5 +1,5 @@
 """Experiment: the bench step captured into hipGraphs (torch.cuda.graph), 1 or 2 HIP streams per clip.
-usage: python tools/diag/graph_step.py [streams] [steps]"""
+usage: python tools/diag/graph_step.py [streams] [steps] [sp] [fp]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -8,9 +8,11 @@ from sfvos_amd import FusedSGD, GradBucket, MSEProxyLoss, PackedClip, SlowFastLa
 
 streams = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+SP = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+FP = int(sys.argv[4]) if len(sys.argv) > 4 else 32
 dev = torch.device('cuda', 0)
 torch.manual_seed(63)
-model = SlowFastLayers(256, dev, 4, 32, precision='bf16').to(dev)
+model = SlowFastLayers(256, dev, SP, FP, precision='bf16').to(dev)
 model.train()
 model.n_streams = streams
 opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
@@ -18,7 +20,7 @@ bucket = GradBucket(opt.flat_grad)
 opt.attach(model, bucket)
 pyr = davis_pyramid()
 gen = torch.Generator(device=dev).manual_seed(63)
-levels = [torch.randn((1, 32, h, w, 256), generator=gen, device=dev).bfloat16() for _, (h, w) in pyr]
+levels = [torch.randn((1, FP, h, w, 256), generator=gen, device=dev).bfloat16() for _, (h, w) in pyr]
 clip = PackedClip.from_levels(levels, keys=[k for k, _ in pyr], layout='grouped')
 del levels
 loss_fn = MSEProxyLoss({k: torch.randn((1, 256, h, w), generator=gen, device=dev) for k, (h, w) in pyr})
