@@ -13,7 +13,8 @@ from .mask_head import (MaskBranch, MaskRCNNHeads, MaskRCNNPredictor, maskrcnn_i
                         maskrcnn_loss, paste_masks_in_image)
 from .parallel import GradBucket, init_distributed  # noqa: F401
 from .roi_align import MultiScaleRoIAlign, roi_align  # noqa: F401
+from .graph import GraphedStep  # noqa: F401
 
 __all__ = ['SlowFastLayers', 'PackedClip', 'SlowFastPlan', 'FusedSGD', 'GradBucket', 'init_distributed',
            'MSEProxyLoss', 'calc_kernel_sizes', 'calc_fuse_kernel_size', 'davis_pyramid', 'union_mask', 'SlowFastStream', 'MaskBranch', 'MaskRCNNHeads', 'MaskRCNNPredictor',
-           'maskrcnn_inference', 'maskrcnn_loss', 'paste_masks_in_image', 'MultiScaleRoIAlign', 'roi_align']
+           'maskrcnn_inference', 'maskrcnn_loss', 'paste_masks_in_image', 'MultiScaleRoIAlign', 'roi_align', 'GraphedStep']

@@ -65,6 +65,11 @@ def parse():
                     help='one all-reduce per layer instead of the 4 coalesced buckets (A/B)')
     ap.add_argument('--cpu-threads', type=int, default=0)
     ap.add_argument('--cpu-clips', type=int, default=5, help='timed clips of the CPU baseline (after 1 warm-up)')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the accumulate-2 cycle from hipGraphs (sfvos_amd.GraphedStep) instead of launching it '
+                         'from Python: same kernels, same order; pays on launch-bound configurations such as the '
+                         "reference's default --sp 1 --fp 1 (one rank only; the dominant kernel's duration then comes "
+                         'from the per-layer pass, events cannot bracket a launch inside a graph)')
     ap.add_argument('--force-dist', action='store_true',
                     help='create the RCCL (nccl) process group even with ONE rank and send the gradient buckets through it '
                          '(an all-reduce over one rank is the identity): the RCCL path of the exchange on a single GPU')
@@ -309,19 +314,28 @@ def main():
     # HIP events in the timed region: around the dominant kernel only (roofline.launch_ms).  An event record between
     # two kernels costs about a microsecond of GPU time and a step has ~100 of them: with every launch bracketed the
     # step is 3 % slower (A/B on one box: 9.70 vs 9.40 ms), so the per-layer table comes from a separate pass below.
+    if args.graph and (dist_on or args.kernel_events == 'all'):
+        sys.exit('--graph: one rank without --force-dist, and not with --kernel-events all')
     timer = model.enable_kernel_timer(None if args.kernel_events == 'all' else
-                                      (['conv_fwd/f1'] if args.kernel_events == 'dominant' else []))
+                                      (['conv_fwd/f1'] if args.kernel_events == 'dominant' and not args.graph else []))
     step = make_step(model, opt, bucket, loss_fn, lambda: model.enhance_packed(clip))
+    run = step
+    if args.graph:
+        from sfvos_amd import GraphedStep
+        gstep = GraphedStep(model, opt, loss_fn, clip, accumulate=2, bucket=bucket)
+        run = lambda i: gstep()   # noqa: E731  (steps and warm-up are even: whole cycles)
+        if args.warmup % 2 or args.steps % 2:
+            sys.exit('--graph: --steps and --warmup must be even (whole accumulate-2 cycles)')
 
     for i in range(args.warmup):
-        step(i)
+        run(i)
     timer.reset()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        run(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -431,6 +445,8 @@ def main():
                        'parallelism': 'dp%d' % world, 'backend': (dist.get_backend() if dist_on else 'none'),
                        'allreduce_collectives_issued': bucket.collectives,
                        'grad_accumulation': 2, 'hip_streams_per_clip': args.streams,
+                       'hip_graph': ('GraphedStep: one hipGraph per clip of the accumulate-2 cycle, replayed; '
+                                     'roofline.launch_ms from the per-layer pass') if args.graph else False,
                        'allreduce_buckets': ('per-layer' if args.per_layer_allreduce else 4) if dist_on else 0},
             'dropin_api_ms_per_step': None if dropin_ms is None else round(dropin_ms, 3),
             'dropin_api_note': 'same step through temporally_enhance_features([slow], [fast]) on fp32 NCHW frame lists '
