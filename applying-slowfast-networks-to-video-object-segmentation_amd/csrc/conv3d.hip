@@ -1192,7 +1192,11 @@ static int make_plan(const sfvos_conv_desc* d, ConvPlan* p) {
     p->family = 2; p->NT = d->dtype == SFVOS_FP8 ? 2 : (d->c_out <= 192 ? 6 : 8) / WNW;
     // one output frame (slow_conv3's forward): 128-channel tiles.  2 ring slots + 2 x 24.5 KB of weights = 76 KB and 103
     // registers, so TWO workgroups share a CU and cover each other's per-stage weight copy (0.208 -> 0.198 ms)
-    if (d->dtype == SFVOS_BF16 && p->t_out == 1 && d->pad_t == 0 && d->c_out > 128) p->NT = 2;
+    int nt2_min = 192;   // (192 channels on 128-channel tiles would multiply 25 % padding: the 192-channel tile stays)
+#ifdef SFVOS_DIAG
+    if (const char* ov = getenv("SFVOS_NT2_MIN")) nt2_min = atoi(ov);
+#endif
+    if (d->dtype == SFVOS_BF16 && p->t_out == 1 && d->pad_t == 0 && d->c_out > nt2_min) p->NT = 2;
     split_frames(p->t_out, d->dtype == SFVOS_FP8 ? 2 : (p->NT == 3 ? 3 : 2), p);
     p->MT = 1; p->TH = 4;
     p->BN = 32 * p->NT * WNW;
