@@ -47,7 +47,10 @@ struct WgradArgs {
 
 // NXS: x tiles a stage may copy ahead (2: one frame per stage is new when t_out > 1; DG: a conv with ONE output frame
 // re-uses nothing between stages -- every stage needs DG new frames -- so the ring holds two stages, R = 2 DG)
-template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS = 2>
+// KS: waves that SHARE one (n-tile, c-tile, dt) group and split the tile's rows between them (summed through LDS at the
+// end, in a fixed order).  fast_conv2 (kt = 11, one n-tile, one c-tile) on 8 taps per workgroup runs taps 8 + 3: five of
+// sixteen wave slots idle; with 4 taps x 2 row halves it runs 4 + 4 + 3.
+template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS = 2, int KS = 1>
 struct WgradCfg {
   static constexpr int CE = Elt<DT>::CE;
   static constexpr int SPP = 32 / CE;            // 16-B slots per pixel per 32-channel tile
@@ -61,7 +64,9 @@ struct WgradCfg {
   static constexpr int DWP = (DY_SLOTS + 63) / 64, XWP = X_SLOTS / 64;
   static constexpr int DY_BYTES = DWP * 1024, X_BYTES = XWP * 1024;
   static constexpr int LDS_BYTES = R * X_BYTES + 2 * DY_BYTES;
-  static_assert(NTN * NTC * DG == 8, "one (n-tile, c-tile, dt) group per wave");
+  static constexpr int THK = TH / KS;             // tile rows per wave
+  static_assert(NTN * NTC * DG * KS == 8 && TH % KS == 0, "KS waves per (n-tile, c-tile, dt) group");
+  static_assert(KS == 1 || (KS == 2 && DT == SFVOS_BF16 && TAPS == 9), "the row split is a bf16 3x3 configuration");
   static_assert(R > DG, "the ring holds the DG frames of a stage plus the one in flight");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
@@ -78,16 +83,17 @@ __device__ __forceinline__ u32x4 join(const u32x2& lo, const u32x2& hi) {
 }
 
 // (the body is a __device__ function: the buffer-descriptor type it uses exists only in device compilation)
-template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS>
+template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS, int KS>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
-  typedef WgradCfg<DT, TAPS, NTN, NTC, DG, TH, R, NXS> C;
+  typedef WgradCfg<DT, TAPS, NTN, NTC, DG, TH, R, NXS, KS> C;
+  constexpr int THK = C::THK;
   constexpr int CE = C::CE, ES = 16 / CE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const xbase = smem;
   char* const dybase = smem + R * C::X_BYTES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nt = wv % NTN, ct = (wv / NTN) % NTC, dg = wv / (NTN * NTC);
+  const int nt = wv % NTN, ct = (wv / NTN) % NTC, dg = (wv / (NTN * NTC)) % DG, ks = wv / (NTN * NTC * DG);
   const int r = lane & 31, hh = lane >> 5;
 
   // XCD-aware order (speed only, never correctness): workgroup ids are dealt round-robin over the 8 XCDs, so XCD x
@@ -215,7 +221,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   // ---- compute side: stage s multiplies dy buffer s&1 with the x frame in ring slot (q0 + dg) % R; while it
   // runs, up to two more x tiles (nx) and the next dy frame (ndy) are copied, piece by piece between MFMA groups.
   constexpr int TROWS = TAPS == 9 ? 3 : 1, TCOLS = TAPS == 9 ? 3 : 1;
-  constexpr int NSTEP = TH * TROWS;
+  constexpr int NSTEP = THK * TROWS;
   constexpr int NCOPY = NXS * NXP + NDY;   // copy slots of a stage: [x tile 0 pieces] ... [x tile NXS-1 pieces][dy pieces]
   static_assert(NCOPY + 2 <= 2 * NSTEP || DT != SFVOS_BF16, "the copies of a stage must fit between its MFMA steps");
   auto compute = [&](int s, int q0, int nx, bool ndy) {
@@ -244,18 +250,19 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
       // lane -> (row q, 4-column group p) of its 16-lane group's 4x16 block; block rows k0..k0+3
       const int gq = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
       const int lane_off = (8 * (gq >> 1) + qq) * C::ROWB + (16 * (gq & 1) + 4 * pp) * 2;
-      const char* dyl = dyb + lane_off;  // every read below adds a compile-time constant (ds_read offset field)
-      const char* xl = xb + lane_off;
+      // every read below adds a compile-time constant (ds_read offset field); row split: this wave's THK rows
+      const char* dyl = dyb + lane_off + ks * (THK * 16 * C::ROWB);
+      const char* xl = xb + lane_off + ks * (THK * C::HC * C::ROWB);
       if constexpr (TAPS == 9) {
         // row walk: step = halo row rr of the x tile.  Its three column-shifted fragments are read ONCE and serve the
         // (output row ty, vertical tap dh) pairs with ty + dh = rr -- up to 9 MFMAs on 9 different accumulators;
         // the dy fragments of rows rr, rr-1, rr-2 stay in a 4-deep rolling buffer.  76 transposed reads per stage
         // instead of 160.  Fragments of step rr+1 are read while the MFMAs of step rr run (pinned order).
-        constexpr int NROW = TH + 2;
+        constexpr int NROW = THK + 2;
         constexpr int CPS = (NCOPY + NROW - 1) / NROW;   // copy slots per row step
         u32x2 ar[4][2], br[2][3][2];
         auto load = [&](int rr) {
-          if (rr < TH) {
+          if (rr < THK) {
             ar[rr & 3][0] = tr_read(dyl + rr * 16 * C::ROWB);
             ar[rr & 3][1] = tr_read(dyl + (rr * 16 + 4) * C::ROWB);
           }
@@ -273,7 +280,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
 #pragma unroll
           for (int dh = 0; dh < 3; ++dh) {
             const int ty = rr - dh;
-            if (ty < 0 || ty >= TH) continue;
+            if (ty < 0 || ty >= THK) continue;
             const u32x4 av = join(ar[ty & 3][0], ar[ty & 3][1]);
 #pragma unroll
             for (int dw = 0; dw < 3; ++dw)
@@ -362,8 +369,33 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     if (++fo == a.t_out) { fo = 0; q0 += dt_live - 1; }
   }
 
+  if constexpr (KS == 2) {
+    // the two row halves of a group: wave w + 4 hands its accumulators to wave w through LDS, five taps per round
+    // (4 waves x 5 tiles x 4 KB = 80 KB), added as (rows 0..THK-1) + (rows THK..): a fixed order
+    constexpr int TPR = 5;
+    static_assert(4 * TPR * 4096 <= C::LDS_BYTES, "hand-over area");
+    float* red = (float*)smem;
+    __syncthreads();   // ring and dy buffers are dead
+#pragma unroll
+    for (int t0 = 0; t0 < TAPS; t0 += TPR) {
+      if (ks == 1) {
+#pragma unroll
+        for (int t = t0; t < t0 + TPR && t < TAPS; ++t)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) red[(((wv - 4) * TPR + (t - t0)) * 16 + e) * 64 + lane] = acc[t][e];
+      }
+      __syncthreads();
+      if (ks == 0) {
+#pragma unroll
+        for (int t = t0; t < t0 + TPR && t < TAPS; ++t)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[t][e] += red[((wv * TPR + (t - t0)) * 16 + e) * 64 + lane];
+      }
+      __syncthreads();
+    }
+  }
   // slab[ps][n][dt][tap][c]
-  if (wave_live) {
+  if (wave_live && ks == 0) {
     const int dt = dt0 + dg, c = c_base + ct * 32 + r;
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap)
@@ -375,9 +407,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   }
 }
 
-template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS = 2>
+template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS = 2, int KS = 1>
 __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
-  wgrad_body<DT, TAPS, NTN, NTC, DG, TH, R, NXS>(a);
+  wgrad_body<DT, TAPS, NTN, NTC, DG, TH, R, NXS, KS>(a);
 }
 
 // grad_w[n][c][dt][tap] (=|+=) sum_ps slab[ps][n][dt][tap][c]
@@ -435,7 +467,7 @@ int launch_wgrad_reduce(const float* slab, int psplit, int c_out, int c_in, int 
 }
 
 struct WgradPlan {
-  int cfg;  // 0: (1,2,4) 3x3 narrow-n ; 1: (2,2,2) 3x3 ; 2: (1,1,8) 3x3 c_in 32 ; 3: (2,1,4) 1x1 ;
+  int cfg;  // 0: (1,2,4) 3x3 narrow-n ; 1: (2,2,2) 3x3 ; 2: (1,1,8) 3x3 c_in 32 (f32) / (1,1,4) x 2 row halves (bf16) ; 3: (2,1,4) 1x1 ;
             // 4: (1,1,8) 3x3 c_in 32 with ONE output frame (bf16): 4-row tiles, ring of two stages
   int NTN, NTC, DG, TH;
   int n_blocks, c_blocks, dt_blocks, psplit, t_out, ntiles;
@@ -466,17 +498,26 @@ static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
   if (d->taps == 1) {
     p->cfg = 3; p->NTN = 2; p->NTC = 1; p->DG = 4;
   } else if (d->c_in <= 32) {
-    p->cfg = 2; p->NTN = 1; p->NTC = 1; p->DG = 8;
+    p->cfg = 2; p->NTN = 1; p->NTC = 1; p->DG = f32 ? 8 : 4;   // bf16: 4 taps x 2 row halves
+#ifdef SFVOS_DIAG
+    if (getenv("SFVOS_WGRAD_KS1")) p->DG = 8;   // A/B: the 8-tap configuration
+#endif
   } else if (d->c_out <= 32) {
     p->cfg = 0; p->NTN = 1; p->NTC = 2; p->DG = 4;
   } else {
     p->cfg = 1; p->NTN = 2; p->NTC = 2; p->DG = 2;
   }
   p->TH = f32 ? 4 : 8;
+  // the row-split configuration: 16-row tiles, 8 rows per wave (72 MFMAs per wave between barriers as in the other
+  // configurations, 27 % less halo per pixel: fast_conv2 0.200 -> 0.184 ms; 8 taps per workgroup: 0.203 ms)
+  if (p->cfg == 2 && !f32 && p->DG == 4) p->TH = 16;
+#ifdef SFVOS_DIAG
+  if (p->cfg == 2 && !f32 && p->DG == 4 && getenv("SFVOS_WGRAD_TH8")) p->TH = 8;   // A/B
+#endif
   if (p->cfg == 2 && !f32 && p->t_out == 1 && d->kt > 1) {
     // fast_conv3 (12 frames -> 1): nothing is re-used between stages, every stage needs DG new x frames.  With the
     // two-tile look-ahead of the other configurations each stage waited a memory round trip for the other six.
-    p->cfg = 4; p->TH = 4;
+    p->cfg = 4; p->TH = 4; p->DG = 8;
   }
   SFVOS_REQUIRE(d->pyr.n_levels >= 1 && d->pyr.n_levels <= SFVOS_MAX_LEVELS, "wgrad: n_levels out of range");
   SFVOS_REQUIRE(d->batch >= 1 && d->t_alloc >= 1 && d->t_offset > -(1 << 20) && d->t_offset < (1 << 20) &&
@@ -534,10 +575,10 @@ static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
   return SFVOS_OK;
 }
 
-template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS = 2>
+template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS = 2, int KS = 1>
 static int launch_wgrad(const WgradArgs& a, long long grid, hipStream_t stream) {
-  typedef WgradCfg<DT, TAPS, NTN, NTC, DG, TH, R, NXS> C;
-  auto kern = wgrad_kernel<DT, TAPS, NTN, NTC, DG, TH, R, NXS>;
+  typedef WgradCfg<DT, TAPS, NTN, NTC, DG, TH, R, NXS, KS> C;
+  auto kern = wgrad_kernel<DT, TAPS, NTN, NTC, DG, TH, R, NXS, KS>;
   static LdsAttrOnce once;
   if (int rc = once.ensure((const void*)kern, C::LDS_BYTES, "wgrad")) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), C::LDS_BYTES, stream, a);
@@ -606,7 +647,10 @@ extern "C" int sfvos_conv3d_wgrad(const sfvos_conv_desc* d, const void* x, const
     // last template argument: x ring slots (R >= 2 DG lets the ring prefetch across pixel-tile boundaries)
     case 0: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 1, 2, 4, 8, 5>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 1, 2, 4, 4, 5>(a, grid, s); break;
     case 1: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 2, 2, 2, 8, 5>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 2, 2, 2, 4, 4>(a, grid, s); break;
-    case 2: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 1, 1, 8, 8, 11>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 1, 1, 8, 4, 10>(a, grid, s); break;
+    case 2: rc = !bf ? launch_wgrad<SFVOS_F32, 9, 1, 1, 8, 4, 10>(a, grid, s)
+                     : p.DG == 4 && p.TH == 16 ? launch_wgrad<SFVOS_BF16, 9, 1, 1, 4, 16, 6, 2, 2>(a, grid, s)
+                     : p.DG == 4 ? launch_wgrad<SFVOS_BF16, 9, 1, 1, 4, 8, 7, 2, 2>(a, grid, s)
+                                 : launch_wgrad<SFVOS_BF16, 9, 1, 1, 8, 8, 11>(a, grid, s); break;
     case 4: rc = launch_wgrad<SFVOS_BF16, 9, 1, 1, 8, 4, 16, 8>(a, grid, s); break;
     default: rc = bf ? launch_wgrad<SFVOS_BF16, 1, 2, 1, 4, 8, 8>(a, grid, s) : launch_wgrad<SFVOS_F32, 1, 2, 1, 4, 4, 8>(a, grid, s); break;
   }

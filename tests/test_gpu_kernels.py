@@ -327,7 +327,8 @@ WGRAD_CASES = [
     (1, 4, [(12, 21), (6, 10)], 256, 32, 2, 9),    # cfg (1,2,4): c_out 32, c_in 256
     (1, 3, [(9, 17)], 256, 192, 2, 9),             # cfg (2,2,2)
     (1, 3, [(6, 10), (3, 4)], 256, 224, 2, 9),     # ragged n blocks
-    (2, 13, [(7, 19), (9, 3)], 32, 32, 11, 9),     # cfg (1,1,8), kt 11 -> two dt groups
+    (2, 13, [(7, 19), (9, 3)], 32, 32, 11, 9),     # c_in 32: f32 cfg (1,1,8), kt 11 -> two dt groups; bf16 4 taps x 2 row halves: three
+    (1, 6, [(21, 19), (40, 10)], 32, 32, 3, 9),    # the same, levels taller than the 16-row tile: both row halves live, 3 of 4 taps
     (1, 9, [(18, 16)], 32, 64, 5, 1),              # cfg (2,1,4) lateral
     (1, 24, [(5, 33), (2, 2)], 32, 64, 20, 1),
 ]
@@ -367,7 +368,7 @@ def test_conv3d_wgrad(lib, prec, case):
 WGRAD_MULTI_TILE_CASES = [
     (1, 13, [(96, 168), (24, 42)], 256, 32, 11, 9),   # cfg (1,2,4): fast_conv1's shape, kt 11 = 4 + 4 + 3 taps
     (1, 3, [(96, 168), (12, 21)], 256, 192, 2, 9),    # cfg (2,2,2): slow_conv1/2's shape
-    (1, 14, [(96, 168)], 32, 32, 11, 9),              # cfg (1,1,8): fast_conv2's shape, t_out 4
+    (1, 14, [(160, 170)], 32, 32, 11, 9),             # fast_conv2's shape (t_out 4): f32 cfg (1,1,8), bf16 4 taps x 2 row halves
     (1, 22, [(96, 168), (5, 9)], 32, 64, 20, 1),      # cfg (2,1,4): the first lateral, kt 20
 ]
 
@@ -392,6 +393,8 @@ def test_conv3d_wgrad_several_tiles_per_workgroup(lib, prec, case):
     nbytes = lib.load().sfvos_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
     psplit = nbytes // (4 * ref.numel())
     th = 4 if prec == 'fp32' else 8
+    if prec == 'bf16' and cin == 32 and taps == 9:
+        th = 16   # the row-split configuration of wgrad_kernel: 16-row tiles, two waves per (tap) group
     ntiles = sum(B * -(-H // th) * -(-W // 16) for H, W in shapes)
     per = -(-ntiles // psplit)
     if taps == 1 and prec == 'bf16':   # lateral_wgrad.hip: 16-position tiles, one slab per workgroup (its own test below)
