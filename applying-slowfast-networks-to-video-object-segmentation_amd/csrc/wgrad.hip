@@ -509,7 +509,9 @@ static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
   }
   p->TH = f32 ? 4 : 8;
   // the row-split configuration: 16-row tiles, 8 rows per wave (72 MFMAs per wave between barriers as in the other
-  // configurations, 27 % less halo per pixel: fast_conv2 0.200 -> 0.184 ms; 8 taps per workgroup: 0.203 ms)
+  // configurations, 27 % less halo per pixel: fast_conv2 0.200 -> 0.184 ms; 8 taps per workgroup: 0.203 ms.  The same
+  // decomposition with one c-tile per workgroup for fast_conv1 (c_in 256) was 3 % slower than (2 c-tiles, 4 taps): 2.58 vs
+  // 2.51 ms, 104 vs 68 MB of slabs)
   if (p->cfg == 2 && !f32 && p->DG == 4) p->TH = 16;
 #ifdef SFVOS_DIAG
   if (p->cfg == 2 && !f32 && p->DG == 4 && getenv("SFVOS_WGRAD_TH8")) p->TH = 8;   // A/B
