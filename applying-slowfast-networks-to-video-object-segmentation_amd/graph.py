@@ -5,7 +5,7 @@ steps after every 2nd clip.  Run eagerly that is ~100 libsfvos launches per clip
 engine thread.  At the headline configuration (4,32) the GPU has 8.8 ms of work per clip and the host keeps up (a graph
 gains 0.5 %), but the reference's DEFAULT configuration (1,1) (constants.py:7-8) has 1.6 ms of GPU work behind 2.4-2.6 ms
 of host work per clip: launch-bound.  `GraphedStep` captures one hipGraph per position of the accumulation cycle (clip 1:
-forward, loss, backward; clip 2: the same + all-reduce hook, SGD, zero_grad) and replays them: 2.55 -> 1.64 ms per clip
+forward, loss, backward; clip 2: the same + all-reduce hook, SGD, zero_grad) and replays them: 2.3-2.6 -> 1.64 ms per clip
 at (1,1) on MI355X, same numbers bit for bit (tests/test_gpu_graph.py).
 
 What a graph fixes in place: every address (the clip buffer, parameters, BN buffers, optimiser state, the loss scalar) and
