@@ -67,6 +67,43 @@ def test_roi_align_matches_the_oracle_forward_and_backward():
         roi_align(feat.to(DEV), ROIS.to(DEV), 14, scale, 0)
 
 
+@pytest.mark.parametrize('seed', range(6))
+def test_roi_align_random_boxes_and_geometries(seed):
+    """Random maps (1-3 images, 8-72 channels, 5-60 px), scales, square output sizes 1-14, sampling ratios 1-4 and 1-40 boxes that
+    may stick out of the map, lie outside it or have no area: forward and backward against the restatement."""
+    import random
+    from sfvos_amd import roi_align
+    rng = random.Random(77 + seed)
+    g = torch.Generator().manual_seed(seed)
+    N, C, H, W = rng.randint(1, 3), 8 * rng.randint(1, 9), rng.randint(5, 60), rng.randint(5, 60)
+    scale = rng.choice([1.0, 0.5, 0.25, 0.125, 1.0 / 3.0])
+    out = rng.randint(1, 14)   # (the restatement is square-only)
+    ratio = rng.randint(1, 4)
+    K = rng.randint(1, 40)
+    ih, iw = H / scale, W / scale
+    rois = []
+    for _ in range(K):
+        x0, y0 = rng.uniform(-0.2 * iw, 1.1 * iw), rng.uniform(-0.2 * ih, 1.1 * ih)
+        w, h = rng.choice([0.0, rng.uniform(0, 0.3 / scale), rng.uniform(0, iw)]), rng.choice([0.0, rng.uniform(0, ih)])
+        rois.append([rng.randrange(N), x0, y0, x0 + w, y0 + h])
+    rois = torch.tensor(rois, dtype=torch.float32)
+    feat = torch.randn(N, C, H, W, generator=g)
+    fr = feat.clone().requires_grad_(True)
+    ref = ref_roi_align(fr, rois, out, scale, ratio)
+    up = torch.randn(ref.shape, generator=g)
+    (ref * up).sum().backward()
+    fg = feat.to(DEV).requires_grad_(True)
+    got = roi_align(fg, rois.to(DEV), out, scale, ratio)
+    (got * up.to(DEV)).sum().backward()
+    assert got.shape == ref.shape
+    scale_f, scale_b = float(ref.abs().max()), float(fr.grad.abs().max())
+    e_f = float((got.detach().cpu() - ref.detach()).abs().max()) / max(scale_f, 1e-6)
+    e_b = float((fg.grad.cpu() - fr.grad).abs().max()) / max(scale_b, 1e-6)
+    print('seed %d: %d x %d x %d x %d, scale %.3f, out %s, ratio %d, %d boxes: fwd %.1e bwd %.1e'
+          % (seed, N, C, H, W, scale, out, ratio, K, e_f, e_b))
+    assert e_f < 1e-5 and e_b < 1e-5
+
+
 def _davis_feats(C, gen):
     from sfvos_amd import davis_pyramid
     return OrderedDict((k, torch.randn(1, C, h, w, generator=gen)) for k, (h, w) in davis_pyramid())
