@@ -217,11 +217,9 @@ static bool lateral_wgrad_plan(const sfvos_conv_desc* d, LatWgPlan* p) {
         d->ld_x >= 32 && d->ld_y % 8 == 0 && d->ld_y >= 64 && d->batch >= 1 && d->pyr.n_levels >= 1 &&
         d->pyr.n_levels <= SFVOS_MAX_LEVELS))
     return false;
-  long long px = 0;
   for (int l = 0; l < d->pyr.n_levels; ++l) {
     if (d->pyr.h[l] < 1 || d->pyr.w[l] < 1) return false;
     if ((long long)d->pyr.h[l] * d->pyr.w[l] * (d->ld_x > d->ld_y ? d->ld_x : d->ld_y) * 2 >= (1ll << 31)) return false;
-    px += (long long)d->batch * d->pyr.h[l] * d->pyr.w[l];
   }
   const int cus = device_cu_count() > 0 ? device_cu_count() : 256;
   // Tap groups.  Measured inside the training step (conv_f2s1, kt = 20 / conv_f2s2, kt = 11; 1, 2, 4 groups): 52.7 / 48.6 /
