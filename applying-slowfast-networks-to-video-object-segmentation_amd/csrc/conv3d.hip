@@ -128,6 +128,17 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ws = wv % WS, wn = wv / WS;
   const int r = lane & 31, hh = lane >> 5;
+  // M16 (bf16): the MFMAs are v_mfma_f32_16x16x32_bf16 -- one instruction consumes a pixel's whole 64-byte channel group
+  // (K = 32), a wave's 32 px x 32 ch tile is four 16 x 16 blocks [pixel half][channel half].  Same LDS images, same
+  // number of 16-byte fragment reads per tap (two pixel halves + two channel halves instead of two k-steps of each
+  // operand), half the accumulator updates per FLOP: under the board's power limit the cheaper instruction is
+  // the faster kernel (timing-only build with two 16x16x32 on each 32x32x16's operands: -3 ... -6 % on the slow pathway).
+#ifdef SFVOS_WIDE_M32  // A/B builds only: the 32x32x16 form
+  constexpr bool M16 = false;
+#else
+  constexpr bool M16 = DT == SFVOS_BF16;
+#endif
+  const int p16 = lane & 15, kg = lane >> 4;
 
   // workgroup -> (level, clip, frame block, channel block, pixel tile)
   int lvl = 0;
@@ -156,7 +167,8 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
   const long long xfs_bytes = a.lv.xfs[lvl] * a.x_pitch_bytes;  // bytes between consecutive frames of this level
   const char* xclip = a.x + (a.lv.xpos[lvl] + b * a.lv.xbs[lvl]) * a.x_pitch_bytes;
 
-  f32x16 acc[TT][MT][NT];
+  f32x16 acc[M16 ? 1 : TT][M16 ? 1 : MT][M16 ? 1 : NT];
+  f32x4 acc4[M16 ? TT : 1][M16 ? MT : 1][M16 ? NT : 1][2][2];  // M16: [pixel half][channel half] blocks of the tile
 #pragma unroll
   for (int j = 0; j < TT; ++j)
 #pragma unroll
@@ -164,7 +176,10 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
 #pragma unroll
       for (int q = 0; q < NT; ++q)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][i][q][e] = 0.f;
+        for (int e = 0; e < 16; ++e) {
+          if constexpr (M16) acc4[j][i][q][e >> 3][(e >> 2) & 1][e & 3] = 0.f;
+          else acc[j][i][q][e] = 0.f;
+        }
 
   // ---- staging: buffer_load ... lds with per-lane offsets fixed for the whole kernel (see conv3d_fs_kernel):
   // padding pixels / frames outside the clip are zero-filled by the descriptor's range check.  Pixel-major halo
@@ -190,6 +205,14 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
 #pragma unroll
     for (int dw = 0; dw < (C::HALO ? 3 : 1); ++dw)
       xsw[st][dw] = ((r + dw) * 4 + ((2 * st + hh) ^ (((r + dw) >> 2) & 3))) * 16;
+  // M16: lane = (pixel p16, 16-byte chunk kg); column shift dw.  The second pixel half is 16 pixels = 1024 bytes further
+  // (16 pixels do not change the swizzle term): a compile-time constant on the read
+  int xsw16[C::HALO ? 3 : 1];
+#pragma unroll
+  for (int dw = 0; dw < (C::HALO ? 3 : 1); ++dw) {
+    const int px = p16 + dw;
+    xsw16[dw] = (px * 4 + (kg ^ ((px >> 2) & 3))) * 16;
+  }
 #pragma unroll
   for (int it = 0; it < NW; ++it) {
     const int sl = it * C::NTHREADS + tid;
@@ -251,6 +274,70 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
     // k-step k = (tap_local, st): a PD-deep register pipeline -- the fragments of step k+PD-1 are read
     // from LDS while the MFMAs of step k run, so the wait in front of a step never covers reads that
     // were issued just before it (counted lgkmcnt, not lgkmcnt(0)).
+    if constexpr (M16) {
+      // A tap = four quadrant steps (pixel half ph, channel half nh) in the order (0,0) (0,1) (1,1) (1,0): consecutive steps
+      // share one operand set, so each set -- A[ph]: TT x MT pixel fragments, B[nh]: NT weight fragments -- is read once per
+      // tap.  Sets are read in the order they are needed, n = 4 tap + {A0, B0, B1, A1}, set n before the MFMAs of step
+      // n - 1 - LA (pinned with sched_barrier: the wait in front of a step never covers reads issued just before it).
+      //   LA = 1: two slots per operand -- B0[t] (live for the whole tap) and B1[t] swap slots from tap to tap, so every new
+      //           set lands in the slot whose set died a step earlier: the register footprint of the old 2-deep pipeline;
+      //   LA = 3: rings of 3 A / 4 B slots, for the tiles whose accumulators leave the registers.
+      constexpr bool DEEP = TT * MT * NT * 16 + 4 * (3 * TT * MT + 4 * NT) <= 170;
+      constexpr int LA = DEEP ? 3 : 1, NA = DEEP ? 3 : 2, NB = DEEP ? 4 : 2;
+      constexpr int NSET = 4 * TPS, NQ = 4 * TPS;
+      constexpr int PPQ = (NPIECE + NQ - 1) / NQ;  // DMA pieces per quadrant step
+      const int dh = (TAPS == 9) ? tg : 0;
+      const char* wbl16 = wbase + (s & 1) * C::W_BYTES + (kg * C::BN + wn * NT * 32 + p16) * 16;
+      const char* xf16[TT];
+#pragma unroll
+      for (int j = 0; j < TT; ++j) xf16[j] = xfl[j] + dh * C::HC * 64;
+      u32x4 as[NA][TT][MT], bs[NB][NT];
+      auto slot_a = [](int t, int ph) { return (2 * t + ph) % NA; };
+      auto slot_b = [](int t, int nh) { return NB == 2 ? ((t & 1) ^ nh) : (2 * t + nh) % NB; };
+      auto load_set = [&](int n) {
+        const int t = n >> 2, w = n & 3, dw = (TAPS == 9) ? t : 0;
+        if (w == 0 || w == 3) {
+          const int ph = w == 3;
+#pragma unroll
+          for (int j = 0; j < TT; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) as[slot_a(t, ph)][j][i] = lds_read16(xf16[j] + xsw16[dw] + (ph * 1024 + i * C::HC * 64));
+        } else {
+          const int nh = w == 2;
+#pragma unroll
+          for (int q = 0; q < NT; ++q)
+            bs[slot_b(t, nh)][q] = lds_read16(wbl16 + (t * 4 * C::BN + q * 32 + nh * 16) * 16);
+        }
+      };
+#pragma unroll
+      for (int n = 0; n <= LA && n < NSET; ++n) load_set(n);
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) {
+        if (k + 1 + LA < NSET) load_set(k + 1 + LA);
+        __builtin_amdgcn_sched_barrier(0);
+        const int t = k >> 2, ph = (k & 3) >> 1, nh = ((k & 3) == 1 || (k & 3) == 2) ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < TT; ++j)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < NT; ++q)
+              // One asm statement per MFMA, accumulator tied ("+v"): through the builtin hipcc gives every 16x16x32 result
+              // a NEW register quadruple (a 128-bit result has no tied form; 220 of 324 MFMAs of the 3 x 3 tile moved
+              // their accumulator) and the 256-register tiles spilled 12-88 bytes per lane into the MFMA loop; tied they
+              // need fewer registers than the 32x32x16 form did (233 against 247).  Wait states (the guide's asm rules):
+              // the operands come from ds_read (hipcc counts those and waits in front of the statement), the only reader
+              // of D inside the loop is the next MFMA of the same accumulator taking it whole as C (chain: none needed),
+              // and the first reader outside is the epilogue, behind the nops that follow the main loop.
+              asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                           : "+v"(acc4[j][i][q][ph][nh]) : "v"(as[slot_a(t, ph)][j][i]), "v"(bs[slot_b(t, nh)][q]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < PPQ; ++u)
+          if (k * PPQ + u < NPIECE) piece(d, k * PPQ + u);
+      }
+      return;
+    }
     constexpr int OPR = F8 ? 8 : 4;  // registers per operand fragment
     constexpr int PD = (!F8 && (WS * WN == 4 || TT * MT * NT * 16 + 3 * (NT + TT * MT) * OPR <= 192)) ? 3 : 2;  // registers
     constexpr int KS = F8 ? TPS : 2 * TPS;
@@ -381,13 +468,16 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
     fslot = wrap(fslot + TT - 1);  // the next chunk's first frame sits behind this chunk's last TT frames
   }
 
+  if constexpr (M16) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last asm MFMAs' D -> the epilogue's VALU reads
   // ---- epilogue --------------------------------------------------------------------------------------
   // Each 32 px x 32 ch accumulator tile goes through a per-wave f32 scratch in LDS (the staging buffers
   // are dead) and leaves as 16-byte chunks: lane -> (pixel, 8 or 4 channels), so a pixel's 32-channel
   // segment is written (and, when accumulating, read) as whole 64/128-byte runs instead of 2-byte pieces.
-  float s1[NT], s2[NT];
+  float s1[NT][M16 ? 2 : 1], s2[NT][M16 ? 2 : 1];  // M16: a lane's channel is nh * 16 + p16
 #pragma unroll
-  for (int q = 0; q < NT; ++q) s1[q] = s2[q] = 0.f;
+  for (int q = 0; q < NT; ++q)
+#pragma unroll
+    for (int nh = 0; nh < (M16 ? 2 : 1); ++nh) s1[q][nh] = s2[q][nh] = 0.f;
   T* yclip = (T*)a.y + (a.lv.ypos[lvl] + b * a.lv.ybs[lvl]) * a.ld_y;
   const long long yfs = a.lv.yfs[lvl];
   __syncthreads();  // every wave has finished reading the ring / weight buffers
@@ -399,6 +489,7 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
     if (nbase >= a.c_out) continue;  // wave-uniform
     const float bias = a.bias ? a.bias[nbase + r] : 0.f;
     const float desc = F8 ? a.bias[a.c_out + nbase + r] : 1.f;  // e4m3: [2][c_out] = (bias, de-quantisation factor)
+    const float bias16[2] = {a.bias ? a.bias[nbase + p16] : 0.f, a.bias ? a.bias[nbase + 16 + p16] : 0.f};
 #pragma unroll
     for (int j = 0; j < TT; ++j) {
       const int to = tb0 + j;
@@ -407,13 +498,29 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
       for (int i = 0; i < MT; ++i) {
         const int h = h0 + ws * MT + i;
         if (h >= H) continue;  // wave-uniform
+        if constexpr (M16) {
+          // block (ph, nh), element e of lane (p16, kg): pixel 16 ph + 4 kg + e, channel 16 nh + p16
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int px = (e & 3) + 8 * (e >> 2) + 4 * hh;
-          float v = F8 ? acc[j][i][q][e] * desc + bias : acc[j][i][q][e] + bias;
-          if (a.relu) v = fmaxf(v, 0.f);
-          scr[px * 33 + r] = v;
-          if (w0 + px < W) { s1[q] += v; s2[q] += v * v; }
+          for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int px = 16 * ph + 4 * kg + e;
+                float v = acc4[j][i][q][ph][nh][e] + bias16[nh];
+                if (a.relu) v = fmaxf(v, 0.f);
+                scr[px * 33 + 16 * nh + p16] = v;
+                if (w0 + px < W) { s1[q][nh] += v; s2[q][nh] += v * v; }
+              }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int px = (e & 3) + 8 * (e >> 2) + 4 * hh;
+            float v = F8 ? acc[j][i][q][e] * desc + bias : acc[j][i][q][e] + bias;
+            if (a.relu) v = fmaxf(v, 0.f);
+            scr[px * 33 + r] = v;
+            if (w0 + px < W) { s1[q][0] += v; s2[q][0] += v * v; }
+          }
         }
         T* yrow = yclip + (to * yfs + (long long)h * W + w0) * a.ld_y + nbase;
 #pragma unroll
@@ -447,10 +554,22 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
     float* red = (float*)smem;  // [NWAVES][NT][32][2]
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
-      const float t1 = s1[q] + __shfl_xor(s1[q], 32), t2 = s2[q] + __shfl_xor(s2[q], 32);
-      if (lane < 32) {
-        red[((wv * NT + q) * 32 + lane) * 2 + 0] = t1;
-        red[((wv * NT + q) * 32 + lane) * 2 + 1] = t2;
+      if constexpr (M16) {
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {  // the four lane groups hold four pixel quarters of channel 16 nh + p16
+          float t1 = s1[q][nh] + __shfl_xor(s1[q][nh], 16), t2 = s2[q][nh] + __shfl_xor(s2[q][nh], 16);
+          t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+          if (lane < 16) {
+            red[((wv * NT + q) * 32 + 16 * nh + lane) * 2 + 0] = t1;
+            red[((wv * NT + q) * 32 + 16 * nh + lane) * 2 + 1] = t2;
+          }
+        }
+      } else {
+        const float t1 = s1[q][0] + __shfl_xor(s1[q][0], 32), t2 = s2[q][0] + __shfl_xor(s2[q][0], 32);
+        if (lane < 32) {
+          red[((wv * NT + q) * 32 + lane) * 2 + 0] = t1;
+          red[((wv * NT + q) * 32 + lane) * 2 + 1] = t2;
+        }
       }
     }
     __syncthreads();
