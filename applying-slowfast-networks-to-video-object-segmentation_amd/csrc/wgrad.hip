@@ -50,7 +50,16 @@ struct WgradArgs {
 // KS: waves that SHARE one (n-tile, c-tile, dt) group and split the tile's rows between them (summed through LDS at the
 // end, in a fixed order).  fast_conv2 (kt = 11, one n-tile, one c-tile) on 8 taps per workgroup runs taps 8 + 3: five of
 // sixteen wave slots idle; with 4 taps x 2 row halves it runs 4 + 4 + 3.
-template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS = 2, int KS = 1>
+// FPR (bf16, 3x3, even t_out): FRAME-PAIRED stages on v_mfma_f32_16x16x32_bf16.  A stage is (tile, output frames fo, fo+1):
+// K = 32 = the 16 pixels of a tile row in frame fo ++ the same 16 pixels in frame fo+1 (any assignment of the reduction
+// index to k works as long as dy and x use the same one), so a fragment is one transposed read from each of two frame
+// buffers -- the same tiles, the same bytes copied and read per frame as the 32x32x16 form, half the accumulator updates
+// per FLOP.  Under the board's power limit (these kernels run at 1.96 GHz of 2.4) the cheaper instruction is
+// the faster kernel: the same operand registers through this shape (timing-only build) took 7 % off fast_conv1's weight
+// gradient.  Wave dt reads x ring frames q0+dt and q0+dt+1, so a stage keeps DG+1 frames and the ring advances two per
+// stage: R >= DG + 3; 6-row tiles make that fit (and divide every DAVIS level height).  LDS rows stay [pixel][32 ch] with
+// their 32-byte halves swapped on every second group of four rows (see the fragment addressing in wgrad_body).
+template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS = 2, int KS = 1, int FPR = 0>
 struct WgradCfg {
   static constexpr int CE = Elt<DT>::CE;
   static constexpr int SPP = 32 / CE;            // 16-B slots per pixel per 32-channel tile
@@ -62,11 +71,16 @@ struct WgradCfg {
   static constexpr int XT_SLOTS = ((NHPOS * SPP + 63) / 64) * 64;  // one 32-channel x halo tile, padded to whole
   static constexpr int X_SLOTS = NTC * XT_SLOTS;                   // 64-slot wave-pieces (a piece = one channel group)
   static constexpr int DWP = (DY_SLOTS + 63) / 64, XWP = X_SLOTS / 64;
-  static constexpr int DY_BYTES = DWP * 1024, X_BYTES = XWP * 1024;
+  static constexpr int FS = FPR ? 2 : 1;          // output frames per stage
+  static constexpr int DYF_BYTES = DWP * 1024;    // one dy frame
+  static constexpr int DY_BYTES = FS * DYF_BYTES, X_BYTES = XWP * 1024;
   static constexpr int LDS_BYTES = R * X_BYTES + 2 * DY_BYTES;
   static constexpr int THK = TH / KS;             // tile rows per wave
+  static constexpr int PF = 3;                    // FPR: x fragments read ahead of their MFMAs
   static_assert(NTN * NTC * DG * KS == 8 && TH % KS == 0, "KS waves per (n-tile, c-tile, dt) group");
   static_assert(KS == 1 || (KS == 2 && DT == SFVOS_BF16 && TAPS == 9), "the row split is a bf16 3x3 configuration");
+  static_assert(!FPR || (DT == SFVOS_BF16 && TAPS == 9 && KS == 1 && NXS == 2 && R >= DG + 3),
+                "frame pairs: bf16 3x3, a stage holds DG + 1 frames and two more are in flight");
   static_assert(R > DG, "the ring holds the DG frames of a stage plus the one in flight");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
@@ -83,9 +97,9 @@ __device__ __forceinline__ u32x4 join(const u32x2& lo, const u32x2& hi) {
 }
 
 // (the body is a __device__ function: the buffer-descriptor type it uses exists only in device compilation)
-template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS, int KS>
+template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS, int KS, int FPR>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
-  typedef WgradCfg<DT, TAPS, NTN, NTC, DG, TH, R, NXS, KS> C;
+  typedef WgradCfg<DT, TAPS, NTN, NTC, DG, TH, R, NXS, KS, FPR> C;
   constexpr int THK = C::THK;
   constexpr int CE = C::CE, ES = 16 / CE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -115,14 +129,21 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   const int tile_begin = ps * per;
   const int tile_end = min(a.ntiles, tile_begin + per);
   const int ntile = max(0, tile_end - tile_begin);
-  const int S = ntile * a.t_out;   // stages (tile, fo)
+  const int S = ntile * (a.t_out / C::FS);   // stages (tile, fo) / (tile, frame pair)
   const int QT = ntile * nxf;      // x tile loads, in the order they are needed
 
-  f32x16 acc[TAPS];
+  // accumulators of the wave's 32 x 32 (n, c) tile, one per spatial tap: a 32x32x16 result tile, or (frame pairs) the
+  // four 16x16x32 result blocks [2 nh + ch] -- element 4 blk + e' of the tile in both forms (slab store below)
+  f32x16 acc[FPR ? 1 : TAPS];
+  f32x4 acc4[FPR ? TAPS : 1][4];
+  auto acc_get = [&](int t, int e) -> float { if constexpr (FPR) return acc4[t][e >> 2][e & 3]; else return acc[t][e]; };
+  auto acc_add = [&](int t, int e, float v) { if constexpr (FPR) acc4[t][e >> 2][e & 3] += v; else acc[t][e] += v; };
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    for (int e = 0; e < 16; ++e) {
+      if constexpr (FPR) acc4[t][e >> 2][e & 3] = 0.f; else acc[t][e] = 0.f;
+    }
 
   const bool wave_live = (n_base + nt * 32 < a.c_out) && (c_base + ct * 32 < a.c_in) && (dg < dt_live);
 
@@ -158,7 +179,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     for (int it = 0; it < NXP; ++it) {
       const int sl = it * 512 + tid;
       const int tct = sl / C::XT_SLOTS, ts = sl - tct * C::XT_SLOTS;
-      const int j = ts % C::SPP, hp = ts / C::SPP;
+      const int jl = ts % C::SPP, hp = ts / C::SPP;
+      // frame pairs: LDS row hp keeps its 16-byte chunks XOR-ed with 2 * ((hp >> 2) & 1) -- see the fragment reads
+      const int j = FPR ? jl ^ (2 * ((hp >> 2) & 1)) : jl;
       const int h = h0 + hp / C::HC - C::HALO, w = w0 + hp % C::HC - C::HALO, c = c_base + tct * 32;
       const bool ok = sl < C::X_SLOTS && hp < C::NHPOS && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W &&
                       c < a.c_in;
@@ -176,7 +199,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
 #pragma unroll
     for (int it = 0; it < NDY; ++it) {
       const int sl = it * 512 + tid;
-      const int j = sl % C::SPP, pos = (sl / C::SPP) % C::NPOS, tnt = sl / (C::SPP * C::NPOS);
+      const int jl = sl % C::SPP, pos = (sl / C::SPP) % C::NPOS, tnt = sl / (C::SPP * C::NPOS);
+      const int j = FPR ? jl ^ (2 * ((pos >> 2) & 1)) : jl;
       const int h = h0 + pos / 16, w = w0 + pos % 16, n = n_base + tnt * 32;
       const bool ok = sl < C::DY_SLOTS && h < H && w < W && n < a.c_out;
       dyo[it] = ok ? (unsigned)((((long long)h * W + w) * a.ld_y + n + j * CE) * ES) : OOB;
@@ -192,11 +216,11 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     c.dst = xbase + (xi_q % R) * C::X_BYTES + lds_wave_off;
     ++xi_f; ++xi_q;
   };
-  auto begin_dy = [&](Copy& c, int s) {  // dy frame of stage s -> buffer s & 1
+  auto begin_dy = [&](Copy& c, int s, int f) {  // next dy frame = frame f (of FS) of stage s -> buffer s & 1
     if (di_fo == a.t_out) { di_fo = 0; enter_tile_dy(++di_tile); }
     c.src = dy_frame0 + (long long)di_fo * dy_fstride;
     c.rec = (int)dy_fstride;
-    c.dst = dybase + (s & 1) * C::DY_BYTES + lds_wave_off;
+    c.dst = dybase + (s & 1) * C::DY_BYTES + f * C::DYF_BYTES + lds_wave_off;
     ++di_fo;
   };
   auto x_piece = [&](const Copy& c, int p) {
@@ -222,7 +246,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
   // runs, up to two more x tiles (nx) and the next dy frame (ndy) are copied, piece by piece between MFMA groups.
   constexpr int TROWS = TAPS == 9 ? 3 : 1, TCOLS = TAPS == 9 ? 3 : 1;
   constexpr int NSTEP = THK * TROWS;
-  constexpr int NCOPY = NXS * NXP + NDY;   // copy slots of a stage: [x tile 0 pieces] ... [x tile NXS-1 pieces][dy pieces]
+  constexpr int NCOPY = NXS * NXP + C::FS * NDY;   // copy slots of a stage: [x tile 0 pieces] ... [x tile NXS-1 pieces][dy pieces of each frame]
   static_assert(NCOPY + 2 <= 2 * NSTEP || DT != SFVOS_BF16, "the copies of a stage must fit between its MFMA steps");
   auto compute = [&](int s, int q0, int nx, bool ndy) {
     const char* dyb = dybase + (s & 1) * C::DY_BYTES + nt * (C::NPOS * C::ROWB);
@@ -238,15 +262,95 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
         }
         return;
       }
-      if (slot == NXS * NXP && ndy) begin_dy(cd, s + 1);
-      if (slot < NCOPY) { if (ndy) dy_piece(cd, slot - NXS * NXP); return; }
+      if (slot < NCOPY && ndy) {
+        const int d = slot - NXS * NXP, f = d / NDY, pc = d - f * NDY;
+        if (pc == 0) begin_dy(cd, s + 1, f);
+        dy_piece(cd, pc);
+      }
     };
     if (!wave_live) {  // nothing to multiply (tap / channel tile past the tensor): just feed the copies
 #pragma unroll
       for (int slot = 0; slot < NCOPY; ++slot) copies(slot);
       return;
     }
-    if constexpr (DT == SFVOS_BF16) {
+    if constexpr (DT == SFVOS_BF16 && FPR) {
+      // ---- frame pairs, 16x16x32 MFMAs: K = the 16 pixels of a tile row in frame fo ++ the same pixels in frame fo + 1.
+      // Operand of a 16-channel half: lane (p16 = channel, g16 = k chunk) holds pixels 4 g16 .. +3 of the row in frame A
+      // (first ds_read_b64_tr_b16) and in frame B (second): dy frames (fo, fo + 1), x ring frames (q0 + dt, q0 + dt + 1).
+      // A 16-lane group reads 4 LDS rows x 32 bytes; the two groups of a half-wave (g16 = 0, 1 / 2, 3) read rows that are
+      // 4 apart, which would collide on 64-byte rows (4 rows = 64 banks) -- so row r keeps its two 32-byte halves swapped
+      // when (r >> 2) & 1 (the copies write it that way, enter_tile_*): rows 4 apart then always sit in different bank
+      // halves.  Byte address of lane (g16, q, p), channel half h, rows from B on:
+      //   64 (B + 4 g16 + q) + 32 (h ^ ((B + 4 g16 + q) >> 2 & 1)) + 8 p  =  (lx[B & 3] ^ 32 (((B >> 2) & 1) ^ h)) + 64 B:
+      // four lane constants, one add per stage, frame and variant, one XOR where the half flips, immediates per read.
+      const int g16 = lane >> 4, p16 = lane & 15, qq = p16 >> 2, pp = p16 & 3;
+      const int xoA = (int)(xb - smem), xoB = (int)(xbase - smem) + ((q0 + dg + 1) % R) * C::X_BYTES + ct * (C::XT_SLOTS * 16);
+      int xa[2][4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int lx = 64 * (4 * g16 + qq) + 8 * pp + 32 * ((g16 + ((v + qq) >> 2)) & 1);
+        xa[0][v] = xoA + lx;
+        xa[1][v] = xoB + lx;
+      }
+      const int ya = (int)(dyb - smem) + 64 * (4 * g16 + qq) + 8 * pp + 32 * (g16 & 1);   // dy rows start at 16 ty: v = 0, par = 0
+      // x fragments in issue order: f = (halo row rr, channel half ch of x, column shift dw); each serves the (tile row
+      // rr - dh, vertical tap dh) pairs that meet its halo row, for both n halves: up to 6 MFMAs.  PF fragments in
+      // flight; the dy rows roll through three slots -- row rr + 1 is read into the slot of row rr - 2 right after that
+      // row's last MFMAs (fragment (rr, 1, 2), vertical tap 2).
+      constexpr int NROW = THK + 2, NFR = NROW * 6;
+      static_assert(NCOPY <= NFR, "one copy slot per x fragment");
+      u32x4 ar[3][2], br[C::PF + 1];
+      auto load_a = [&](int ty) {
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+          const int y = (nh ? ya ^ 32 : ya) + ty * 16 * C::ROWB;
+          ar[ty % 3][nh] = join(tr_read(smem + y), tr_read(smem + y + C::DYF_BYTES));
+        }
+      };
+      auto load_b = [&](int f) {
+        const int rr = f / 6, ch = (f / 3) & 1, dw = f % 3;
+        const int rb = rr * C::HC + dw, v = rb & 3, flip = ((rb >> 2) & 1) ^ ch;   // row base of the fragment
+        br[f % (C::PF + 1)] = join(tr_read(smem + (flip ? xa[0][v] ^ 32 : xa[0][v]) + rb * C::ROWB),
+                                   tr_read(smem + (flip ? xa[1][v] ^ 32 : xa[1][v]) + rb * C::ROWB));
+      };
+      auto mma = [&](int f, int dh) {
+        const int rr = f / 6, ch = (f / 3) & 1, dw = f % 3, ty = rr - dh;
+        if (ty < 0 || ty >= THK) return;
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+          // block (n half, c half) of the 32 x 32 tile.  One asm statement per MFMA with the accumulator tied: through the
+          // builtin hipcc gives every 128-bit MFMA result a new register quadruple (no tied form) and the rotation costs
+          // ~36 registers.  Operands come from ds_read (hipcc waits in front of the statement); inside the loop D is
+          // read only by the next MFMA of the same accumulator, whole, as C; the slab stores sit behind nops.
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0"
+                       : "+v"(acc4[dh * 3 + dw][2 * nh + ch]) : "v"(ar[ty % 3][nh]), "v"(br[f % (C::PF + 1)]));
+      };
+      load_a(0);
+      if (THK > 1) load_a(1);
+#pragma unroll
+      for (int f = 0; f < C::PF; ++f) load_b(f);
+#pragma unroll
+      for (int rr = 0; rr < NROW; ++rr)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+          for (int dw = 0; dw < 3; ++dw) {
+            const int f = (rr * 2 + ch) * 3 + dw;
+            if (f + C::PF < NFR) load_b(f + C::PF);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(f, 2);
+            if (ch == 1 && dw == 2 && rr >= 1 && rr + 1 < THK) {   // row rr - 2 is dead (or never existed): fetch row rr + 1
+              __builtin_amdgcn_sched_barrier(0);
+              load_a(rr + 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            mma(f, 1);
+            mma(f, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            copies(f);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+    } else if constexpr (DT == SFVOS_BF16) {
       // lane -> (row q, 4-column group p) of its 16-lane group's 4x16 block; block rows k0..k0+3
       const int gq = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3;
       const int lane_off = (8 * (gq >> 1) + qq) * C::ROWB + (16 * (gq & 1) + 4 * pp) * 2;
@@ -346,14 +450,17 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
 
   // ---- main loop ----------------------------------------------------------------------------------------
   if (S > 0) {
-    Copy c;
-    begin_dy(c, 0);
 #pragma unroll
-    for (int p = 0; p < NDY; ++p) dy_piece(c, p);
+    for (int f = 0; f < C::FS; ++f) {
+      Copy c;
+      begin_dy(c, 0, f);
+#pragma unroll
+      for (int p = 0; p < NDY; ++p) dy_piece(c, p);
+    }
   }
   int q0 = 0, fo = 0;  // first x load of the stage (tile_local * nxf + fo), dy frame of the stage
   for (int s = 0; s < S; ++s) {
-    const int need = q0 + dt_live - 1;  // last x load this stage reads
+    const int need = q0 + dt_live - 1 + (C::FS - 1);  // last x load this stage reads
     if (xi_q <= need) {
       // not yet copied (start of the sweep, or a tile boundary the ring could not prefetch across): every wave
       // is done with the previous stage after this barrier, so the slots of its frames may be overwritten
@@ -365,10 +472,11 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     // loads q < q0 + R overwrite frames that no stage >= s reads
     const int nx = max(0, min(NXS, min(QT, q0 + R) - xi_q));
     compute(s, q0, nx, s + 1 < S);
-    ++q0;
-    if (++fo == a.t_out) { fo = 0; q0 += dt_live - 1; }
+    q0 += C::FS;
+    if ((fo += C::FS) == a.t_out) { fo = 0; q0 += dt_live - 1; }
   }
 
+  if constexpr (FPR) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last asm MFMAs' D -> the VALU reads below
   if constexpr (KS == 2) {
     // the two row halves of a group: wave w + 4 hands its accumulators to wave w through LDS, five taps per round
     // (4 waves x 5 tiles x 4 KB = 80 KB), added as (rows 0..THK-1) + (rows THK..): a fixed order
@@ -382,34 +490,37 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
 #pragma unroll
         for (int t = t0; t < t0 + TPR && t < TAPS; ++t)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) red[(((wv - 4) * TPR + (t - t0)) * 16 + e) * 64 + lane] = acc[t][e];
+          for (int e = 0; e < 16; ++e) red[(((wv - 4) * TPR + (t - t0)) * 16 + e) * 64 + lane] = acc_get(t, e);
       }
       __syncthreads();
       if (ks == 0) {
 #pragma unroll
         for (int t = t0; t < t0 + TPR && t < TAPS; ++t)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) acc[t][e] += red[((wv * TPR + (t - t0)) * 16 + e) * 64 + lane];
+          for (int e = 0; e < 16; ++e) acc_add(t, e, red[((wv * TPR + (t - t0)) * 16 + e) * 64 + lane]);
       }
       __syncthreads();
     }
   }
   // slab[ps][n][dt][tap][c]
   if (wave_live && ks == 0) {
-    const int dt = dt0 + dg, c = c_base + ct * 32 + r;
+    const int dt = dt0 + dg;
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int n = n_base + nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        a.slab[((((long long)ps * a.c_out + n) * a.kt + dt) * TAPS + tap) * a.c_in + c] = acc[tap][e];
+        // 32x32x16: element e of lane (r, hh) = row (e & 3) + 8 (e >> 2) + 4 hh, column r;  16x16x32 blocks: element
+        // 4 (2 nh + ch) + e' of lane (p16, g16) = row 16 nh + 4 g16 + e', column 16 ch + p16
+        const int n = n_base + nt * 32 + (FPR ? 16 * (e >> 3) + 4 * (lane >> 4) + (e & 3) : (e & 3) + 8 * (e >> 2) + 4 * hh);
+        const int c = c_base + ct * 32 + (FPR ? 16 * ((e >> 2) & 1) + (lane & 15) : r);
+        a.slab[((((long long)ps * a.c_out + n) * a.kt + dt) * TAPS + tap) * a.c_in + c] = acc_get(tap, e);
       }
   }
 }
 
-template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS = 2, int KS = 1>
+template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS = 2, int KS = 1, int FPR = 0>
 __global__ __launch_bounds__(512) void wgrad_kernel(WgradArgs a) {
-  wgrad_body<DT, TAPS, NTN, NTC, DG, TH, R, NXS, KS>(a);
+  wgrad_body<DT, TAPS, NTN, NTC, DG, TH, R, NXS, KS, FPR>(a);
 }
 
 // grad_w[n][c][dt][tap] (=|+=) sum_ps slab[ps][n][dt][tap][c]
@@ -469,7 +580,7 @@ int launch_wgrad_reduce(const float* slab, int psplit, int c_out, int c_in, int 
 struct WgradPlan {
   int cfg;  // 0: (1,2,4) 3x3 narrow-n ; 1: (2,2,2) 3x3 ; 2: (1,1,8) 3x3 c_in 32 (f32) / (1,1,4) x 2 row halves (bf16) ; 3: (2,1,4) 1x1 ;
             // 4: (1,1,8) 3x3 c_in 32 with ONE output frame (bf16): 4-row tiles, ring of two stages
-  int NTN, NTC, DG, TH;
+  int NTN, NTC, DG, TH, FPR;   // FPR: frame-paired stages on 16x16x32 MFMAs (bf16 3x3, c_in >= 64, even t_out)
   int n_blocks, c_blocks, dt_blocks, psplit, t_out, ntiles;
   WgradLevels lv;
 };
@@ -508,12 +619,18 @@ static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
     p->cfg = 1; p->NTN = 2; p->NTC = 2; p->DG = 2;
   }
   p->TH = f32 ? 4 : 8;
+  p->FPR = 0;
   // the row-split configuration: 16-row tiles, 8 rows per wave (72 MFMAs per wave between barriers as in the other
   // configurations, 27 % less halo per pixel: fast_conv2 0.200 -> 0.184 ms; 8 taps per workgroup: 0.203 ms.  The same
   // decomposition with one c-tile per workgroup for fast_conv1 (c_in 256) was 3 % slower than (2 c-tiles, 4 taps): 2.58 vs
   // 2.51 ms, 104 vs 68 MB of slabs)
   if (p->cfg == 2 && !f32 && p->DG == 4) p->TH = 16;
+  // bf16 3x3 layers with c_in >= 64 and an even number >= 4 of output frames: frame-paired stages on
+  // v_mfma_f32_16x16x32_bf16, 6-row tiles (see WgradCfg): fast_conv1 2.46 -> 2.36 ms.  With t_out = 2 a tile is ONE stage
+  // and every stage starts with the tile-boundary refill of the ring: slow_conv2 0.27 -> 0.30 ms, left on the 32x32x16 form
+  if (!f32 && d->taps == 9 && (p->cfg == 0 || p->cfg == 1) && p->t_out % 2 == 0 && p->t_out >= 4) { p->FPR = 1; p->TH = 6; }
 #ifdef SFVOS_DIAG
+  if (getenv("SFVOS_WGRAD_M32") && p->FPR) { p->FPR = 0; p->TH = 8; }   // A/B: the 32x32x16 configurations
   if (p->cfg == 2 && !f32 && p->DG == 4 && getenv("SFVOS_WGRAD_TH8")) p->TH = 8;   // A/B
 #endif
   if (p->cfg == 2 && !f32 && p->t_out == 1 && d->kt > 1) {
@@ -577,10 +694,10 @@ static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
   return SFVOS_OK;
 }
 
-template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS = 2, int KS = 1>
+template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS = 2, int KS = 1, int FPR = 0>
 static int launch_wgrad(const WgradArgs& a, long long grid, hipStream_t stream) {
-  typedef WgradCfg<DT, TAPS, NTN, NTC, DG, TH, R, NXS, KS> C;
-  auto kern = wgrad_kernel<DT, TAPS, NTN, NTC, DG, TH, R, NXS, KS>;
+  typedef WgradCfg<DT, TAPS, NTN, NTC, DG, TH, R, NXS, KS, FPR> C;
+  auto kern = wgrad_kernel<DT, TAPS, NTN, NTC, DG, TH, R, NXS, KS, FPR>;
   static LdsAttrOnce once;
   if (int rc = once.ensure((const void*)kern, C::LDS_BYTES, "wgrad")) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), C::LDS_BYTES, stream, a);
@@ -647,8 +764,12 @@ extern "C" int sfvos_conv3d_wgrad(const sfvos_conv_desc* d, const void* x, const
   const bool bf = d->dtype == SFVOS_BF16;
   switch (p.cfg) {
     // last template argument: x ring slots (R >= 2 DG lets the ring prefetch across pixel-tile boundaries)
-    case 0: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 1, 2, 4, 8, 5>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 1, 2, 4, 4, 5>(a, grid, s); break;
-    case 1: rc = bf ? launch_wgrad<SFVOS_BF16, 9, 2, 2, 2, 8, 5>(a, grid, s) : launch_wgrad<SFVOS_F32, 9, 2, 2, 2, 4, 4>(a, grid, s); break;
+    case 0: rc = !bf ? launch_wgrad<SFVOS_F32, 9, 1, 2, 4, 4, 5>(a, grid, s)
+                     : p.FPR ? launch_wgrad<SFVOS_BF16, 9, 1, 2, 4, 6, 7, 2, 1, 1>(a, grid, s)
+                                  : launch_wgrad<SFVOS_BF16, 9, 1, 2, 4, 8, 5>(a, grid, s); break;
+    case 1: rc = !bf ? launch_wgrad<SFVOS_F32, 9, 2, 2, 2, 4, 4>(a, grid, s)
+                     : p.FPR ? launch_wgrad<SFVOS_BF16, 9, 2, 2, 2, 6, 5, 2, 1, 1>(a, grid, s)
+                                  : launch_wgrad<SFVOS_BF16, 9, 2, 2, 2, 8, 5>(a, grid, s); break;
     case 2: rc = !bf ? launch_wgrad<SFVOS_F32, 9, 1, 1, 8, 4, 10>(a, grid, s)
                      : p.DG == 4 && p.TH == 16 ? launch_wgrad<SFVOS_BF16, 9, 1, 1, 4, 16, 6, 2, 2>(a, grid, s)
                      : p.DG == 4 ? launch_wgrad<SFVOS_BF16, 9, 1, 1, 4, 8, 7, 2, 2>(a, grid, s)

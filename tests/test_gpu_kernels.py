@@ -327,6 +327,8 @@ WGRAD_CASES = [
     (1, 4, [(12, 21), (6, 10)], 256, 32, 2, 9),    # cfg (1,2,4): c_out 32, c_in 256
     (1, 3, [(9, 17)], 256, 192, 2, 9),             # cfg (2,2,2)
     (1, 3, [(6, 10), (3, 4)], 256, 224, 2, 9),     # ragged n blocks
+    (1, 5, [(12, 21), (6, 10)], 256, 32, 2, 9),    # cfg (1,2,4) with an even number of output frames: bf16 frame-paired stages
+    (2, 8, [(7, 19), (13, 5)], 64, 32, 3, 9),      # the same: two clips, c_in 64 (one c block), t_out 6, 3 of 4 taps live
     (2, 13, [(7, 19), (9, 3)], 32, 32, 11, 9),     # c_in 32: f32 cfg (1,1,8), kt 11 -> two dt groups; bf16 4 taps x 2 row halves: three
     (1, 6, [(21, 19), (40, 10)], 32, 32, 3, 9),    # the same, levels taller than the 16-row tile: both row halves live, 3 of 4 taps
     (1, 9, [(18, 16)], 32, 64, 5, 1),              # cfg (2,1,4) lateral
@@ -368,6 +370,7 @@ def test_conv3d_wgrad(lib, prec, case):
 WGRAD_MULTI_TILE_CASES = [
     (1, 13, [(96, 168), (24, 42)], 256, 32, 11, 9),   # cfg (1,2,4): fast_conv1's shape, kt 11 = 4 + 4 + 3 taps
     (1, 3, [(96, 168), (12, 21)], 256, 192, 2, 9),    # cfg (2,2,2): slow_conv1/2's shape
+    (1, 14, [(96, 168), (24, 42)], 256, 32, 11, 9),   # fast_conv1's shape with t_out 4: bf16 frame pairs, ring advancing two frames per stage
     (1, 14, [(160, 170)], 32, 32, 11, 9),             # fast_conv2's shape (t_out 4): f32 cfg (1,1,8), bf16 4 taps x 2 row halves
     (1, 22, [(96, 168), (5, 9)], 32, 64, 20, 1),      # cfg (2,1,4): the first lateral, kt 20
 ]
@@ -395,6 +398,8 @@ def test_conv3d_wgrad_several_tiles_per_workgroup(lib, prec, case):
     th = 4 if prec == 'fp32' else 8
     if prec == 'bf16' and cin == 32 and taps == 9:
         th = 16   # the row-split configuration of wgrad_kernel: 16-row tiles, two waves per (tap) group
+    elif prec == 'bf16' and taps == 9 and t_out % 2 == 0 and t_out >= 4:
+        th = 6    # frame-paired stages (two output frames per stage, 16x16x32 MFMAs): 6-row tiles
     ntiles = sum(B * -(-H // th) * -(-W // 16) for H, W in shapes)
     per = -(-ntiles // psplit)
     if taps == 1 and prec == 'bf16':   # lateral_wgrad.hip: 16-position tiles, one slab per workgroup (its own test below)
