@@ -59,6 +59,9 @@ struct WgradArgs {
 // gradient.  Wave dt reads x ring frames q0+dt and q0+dt+1, so a stage keeps DG+1 frames and the ring advances two per
 // stage: R >= DG + 3; 6-row tiles make that fit (and divide every DAVIS level height).  LDS rows stay [pixel][32 ch] with
 // their 32-byte halves swapped on every second group of four rows (see the fragment addressing in wgrad_body).
+// FPR = 2 (bf16, 3x3, any t_out): ROW-PAIRED 16x16x32 -- K = the 16 pixels of tile row r ++ those of row r + THK/2 of the
+// SAME frame (second read = first + a constant), stages and ring as in the 32x32x16 form; 16 % more transposed reads (the
+// row walk covers 6 pair rows x 3 shifts x 2 channel halves instead of 10 rows x 3 shifts), no other change.
 template <int DT, int TAPS, int NTN, int NTC, int DG, int TH, int R, int NXS = 2, int KS = 1, int FPR = 0>
 struct WgradCfg {
   static constexpr int CE = Elt<DT>::CE;
@@ -71,7 +74,7 @@ struct WgradCfg {
   static constexpr int XT_SLOTS = ((NHPOS * SPP + 63) / 64) * 64;  // one 32-channel x halo tile, padded to whole
   static constexpr int X_SLOTS = NTC * XT_SLOTS;                   // 64-slot wave-pieces (a piece = one channel group)
   static constexpr int DWP = (DY_SLOTS + 63) / 64, XWP = X_SLOTS / 64;
-  static constexpr int FS = FPR ? 2 : 1;          // output frames per stage
+  static constexpr int FS = FPR == 1 ? 2 : 1;     // output frames per stage
   static constexpr int DYF_BYTES = DWP * 1024;    // one dy frame
   static constexpr int DY_BYTES = FS * DYF_BYTES, X_BYTES = XWP * 1024;
   static constexpr int LDS_BYTES = R * X_BYTES + 2 * DY_BYTES;
@@ -79,8 +82,11 @@ struct WgradCfg {
   static constexpr int PF = 3;                    // FPR: x fragments read ahead of their MFMAs
   static_assert(NTN * NTC * DG * KS == 8 && TH % KS == 0, "KS waves per (n-tile, c-tile, dt) group");
   static_assert(KS == 1 || (KS == 2 && DT == SFVOS_BF16 && TAPS == 9), "the row split is a bf16 3x3 configuration");
-  static_assert(!FPR || (DT == SFVOS_BF16 && TAPS == 9 && KS == 1 && NXS == 2 && R >= DG + 3),
+  static constexpr int RU = FPR == 2 ? THK / 2 : THK;   // rows a wave walks (row pairs: pair p = rows p and p + RU)
+  static_assert(FPR != 1 || (DT == SFVOS_BF16 && TAPS == 9 && KS == 1 && NXS == 2 && R >= DG + 3),
                 "frame pairs: bf16 3x3, a stage holds DG + 1 frames and two more are in flight");
+  static_assert(FPR != 2 || (DT == SFVOS_BF16 && TAPS == 9 && THK % 2 == 0 && (RU * HC) % 8 == 0),
+                "row pairs: bf16 3x3; the second row of a pair keeps the first one's swizzle state (a multiple of 8 LDS rows on)");
   static_assert(R > DG, "the ring holds the DG frames of a stage plus the one in flight");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
@@ -284,7 +290,11 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
       //   64 (B + 4 g16 + q) + 32 (h ^ ((B + 4 g16 + q) >> 2 & 1)) + 8 p  =  (lx[B & 3] ^ 32 (((B >> 2) & 1) ^ h)) + 64 B:
       // four lane constants, one add per stage, frame and variant, one XOR where the half flips, immediates per read.
       const int g16 = lane >> 4, p16 = lane & 15, qq = p16 >> 2, pp = p16 & 3;
-      const int xoA = (int)(xb - smem), xoB = (int)(xbase - smem) + ((q0 + dg + 1) % R) * C::X_BYTES + ct * (C::XT_SLOTS * 16);
+      // second read of a fragment: the next ring frame / dy frame (frame pairs) or RU tile rows further (row pairs)
+      const int xoA = (int)(xb - smem) + ks * (THK * C::HC * C::ROWB);
+      const int xoB = FPR == 1 ? (int)(xbase - smem) + ((q0 + dg + 1) % R) * C::X_BYTES + ct * (C::XT_SLOTS * 16)
+                               : xoA + C::RU * C::HC * C::ROWB;
+      constexpr int DYB = FPR == 1 ? C::DYF_BYTES : C::RU * 16 * C::ROWB;
       int xa[2][4];
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
@@ -292,19 +302,19 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
         xa[0][v] = xoA + lx;
         xa[1][v] = xoB + lx;
       }
-      const int ya = (int)(dyb - smem) + 64 * (4 * g16 + qq) + 8 * pp + 32 * (g16 & 1);   // dy rows start at 16 ty: v = 0, par = 0
+      const int ya = (int)(dyb - smem) + ks * (THK * 16 * C::ROWB) + 64 * (4 * g16 + qq) + 8 * pp + 32 * (g16 & 1);   // dy rows start at 16 ty: v = 0, par = 0
       // x fragments in issue order: f = (halo row rr, channel half ch of x, column shift dw); each serves the (tile row
       // rr - dh, vertical tap dh) pairs that meet its halo row, for both n halves: up to 6 MFMAs.  PF fragments in
       // flight; the dy rows roll through three slots -- row rr + 1 is read into the slot of row rr - 2 right after that
       // row's last MFMAs (fragment (rr, 1, 2), vertical tap 2).
-      constexpr int NROW = THK + 2, NFR = NROW * 6;
+      constexpr int RU = C::RU, NROW = RU + 2, NFR = NROW * 6;
       static_assert(NCOPY <= NFR, "one copy slot per x fragment");
       u32x4 ar[3][2], br[C::PF + 1];
       auto load_a = [&](int ty) {
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh) {
           const int y = (nh ? ya ^ 32 : ya) + ty * 16 * C::ROWB;
-          ar[ty % 3][nh] = join(tr_read(smem + y), tr_read(smem + y + C::DYF_BYTES));
+          ar[ty % 3][nh] = join(tr_read(smem + y), tr_read(smem + y + DYB));
         }
       };
       auto load_b = [&](int f) {
@@ -315,7 +325,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
       };
       auto mma = [&](int f, int dh) {
         const int rr = f / 6, ch = (f / 3) & 1, dw = f % 3, ty = rr - dh;
-        if (ty < 0 || ty >= THK) return;
+        if (ty < 0 || ty >= RU) return;
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh)
           // block (n half, c half) of the 32 x 32 tile.  One asm statement per MFMA with the accumulator tied: through the
@@ -326,7 +336,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
                        : "+v"(acc4[dh * 3 + dw][2 * nh + ch]) : "v"(ar[ty % 3][nh]), "v"(br[f % (C::PF + 1)]));
       };
       load_a(0);
-      if (THK > 1) load_a(1);
+      if (RU > 1) load_a(1);
 #pragma unroll
       for (int f = 0; f < C::PF; ++f) load_b(f);
 #pragma unroll
@@ -339,7 +349,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
             if (f + C::PF < NFR) load_b(f + C::PF);
             __builtin_amdgcn_sched_barrier(0);
             mma(f, 2);
-            if (ch == 1 && dw == 2 && rr >= 1 && rr + 1 < THK) {   // row rr - 2 is dead (or never existed): fetch row rr + 1
+            if (ch == 1 && dw == 2 && rr >= 1 && rr + 1 < RU) {   // row rr - 2 is dead (or never existed): fetch row rr + 1
               __builtin_amdgcn_sched_barrier(0);
               load_a(rr + 1);
               __builtin_amdgcn_sched_barrier(0);
@@ -580,7 +590,7 @@ int launch_wgrad_reduce(const float* slab, int psplit, int c_out, int c_in, int 
 struct WgradPlan {
   int cfg;  // 0: (1,2,4) 3x3 narrow-n ; 1: (2,2,2) 3x3 ; 2: (1,1,8) 3x3 c_in 32 (f32) / (1,1,4) x 2 row halves (bf16) ; 3: (2,1,4) 1x1 ;
             // 4: (1,1,8) 3x3 c_in 32 with ONE output frame (bf16): 4-row tiles, ring of two stages
-  int NTN, NTC, DG, TH, FPR;   // FPR: frame-paired stages on 16x16x32 MFMAs (bf16 3x3, c_in >= 64, even t_out)
+  int NTN, NTC, DG, TH, FPR;   // FPR: 16x16x32 MFMAs, 1 = frame-paired stages (bf16 3x3, c_in >= 64, even t_out >= 4), 2 = row pairs
   int n_blocks, c_blocks, dt_blocks, psplit, t_out, ntiles;
   WgradLevels lv;
 };
@@ -629,14 +639,17 @@ static int make_wgrad_plan(const sfvos_conv_desc* d, WgradPlan* p) {
   // v_mfma_f32_16x16x32_bf16, 6-row tiles (see WgradCfg): fast_conv1 2.46 -> 2.36 ms.  With t_out = 2 a tile is ONE stage
   // and every stage starts with the tile-boundary refill of the ring: slow_conv2 0.27 -> 0.30 ms, left on the 32x32x16 form
   if (!f32 && d->taps == 9 && (p->cfg == 0 || p->cfg == 1) && p->t_out % 2 == 0 && p->t_out >= 4) { p->FPR = 1; p->TH = 6; }
+  // every other bf16 3x3 configuration of 8 rows per wave: row-paired 16x16x32 (see WgradCfg)
+  else if (!f32 && d->taps == 9 && (p->cfg == 0 || p->cfg == 1 || (p->cfg == 2 && p->DG == 4 && p->TH == 16))) p->FPR = 2;
 #ifdef SFVOS_DIAG
-  if (getenv("SFVOS_WGRAD_M32") && p->FPR) { p->FPR = 0; p->TH = 8; }   // A/B: the 32x32x16 configurations
+  if (getenv("SFVOS_WGRAD_M32") && p->FPR) { p->TH = p->FPR == 1 ? 8 : p->TH; p->FPR = 0; }   // A/B: the 32x32x16 configurations
+  if (getenv("SFVOS_WGRAD_RPR") && p->FPR == 1) { p->TH = 8; p->FPR = 2; }                     // A/B: row pairs where frame pairs apply
   if (p->cfg == 2 && !f32 && p->DG == 4 && getenv("SFVOS_WGRAD_TH8")) p->TH = 8;   // A/B
 #endif
   if (p->cfg == 2 && !f32 && p->t_out == 1 && d->kt > 1) {
     // fast_conv3 (12 frames -> 1): nothing is re-used between stages, every stage needs DG new x frames.  With the
     // two-tile look-ahead of the other configurations each stage waited a memory round trip for the other six.
-    p->cfg = 4; p->TH = 4; p->DG = 8;
+    p->cfg = 4; p->TH = 4; p->DG = 8; p->FPR = 0;
   }
   SFVOS_REQUIRE(d->pyr.n_levels >= 1 && d->pyr.n_levels <= SFVOS_MAX_LEVELS, "wgrad: n_levels out of range");
   SFVOS_REQUIRE(d->batch >= 1 && d->t_alloc >= 1 && d->t_offset > -(1 << 20) && d->t_offset < (1 << 20) &&
@@ -765,12 +778,15 @@ extern "C" int sfvos_conv3d_wgrad(const sfvos_conv_desc* d, const void* x, const
   switch (p.cfg) {
     // last template argument: x ring slots (R >= 2 DG lets the ring prefetch across pixel-tile boundaries)
     case 0: rc = !bf ? launch_wgrad<SFVOS_F32, 9, 1, 2, 4, 4, 5>(a, grid, s)
-                     : p.FPR ? launch_wgrad<SFVOS_BF16, 9, 1, 2, 4, 6, 7, 2, 1, 1>(a, grid, s)
+                     : p.FPR == 1 ? launch_wgrad<SFVOS_BF16, 9, 1, 2, 4, 6, 7, 2, 1, 1>(a, grid, s)
+                     : p.FPR == 2 ? launch_wgrad<SFVOS_BF16, 9, 1, 2, 4, 8, 5, 2, 1, 2>(a, grid, s)
                                   : launch_wgrad<SFVOS_BF16, 9, 1, 2, 4, 8, 5>(a, grid, s); break;
     case 1: rc = !bf ? launch_wgrad<SFVOS_F32, 9, 2, 2, 2, 4, 4>(a, grid, s)
-                     : p.FPR ? launch_wgrad<SFVOS_BF16, 9, 2, 2, 2, 6, 5, 2, 1, 1>(a, grid, s)
+                     : p.FPR == 1 ? launch_wgrad<SFVOS_BF16, 9, 2, 2, 2, 6, 5, 2, 1, 1>(a, grid, s)
+                     : p.FPR == 2 ? launch_wgrad<SFVOS_BF16, 9, 2, 2, 2, 8, 5, 2, 1, 2>(a, grid, s)
                                   : launch_wgrad<SFVOS_BF16, 9, 2, 2, 2, 8, 5>(a, grid, s); break;
     case 2: rc = !bf ? launch_wgrad<SFVOS_F32, 9, 1, 1, 8, 4, 10>(a, grid, s)
+                     : p.DG == 4 && p.TH == 16 && p.FPR == 2 ? launch_wgrad<SFVOS_BF16, 9, 1, 1, 4, 16, 6, 2, 2, 2>(a, grid, s)
                      : p.DG == 4 && p.TH == 16 ? launch_wgrad<SFVOS_BF16, 9, 1, 1, 4, 16, 6, 2, 2>(a, grid, s)
                      : p.DG == 4 ? launch_wgrad<SFVOS_BF16, 9, 1, 1, 4, 8, 7, 2, 2>(a, grid, s)
                                  : launch_wgrad<SFVOS_BF16, 9, 1, 1, 8, 8, 11>(a, grid, s); break;
