@@ -205,12 +205,16 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
 #pragma unroll
     for (int dw = 0; dw < (C::HALO ? 3 : 1); ++dw)
       xsw[st][dw] = ((r + dw) * 4 + ((2 * st + hh) ^ (((r + dw) >> 2) & 3))) * 16;
-  // M16: lane = (pixel p16, 16-byte chunk kg); column shift dw.  The second pixel half is 16 pixels = 1024 bytes further
-  // (16 pixels do not change the swizzle term): a compile-time constant on the read
+  // M16: lane = (MFMA row p16, 16-byte chunk kg); column shift dw.  Row p16 of the operand is pixel 4 (p16 & 3) + (p16 >> 2)
+  // of the half (any assignment of pixels to rows works, the epilogue undoes it): with rows = consecutive pixels the
+  // ds_read_b128 lane groups ({0-3, 12-15, 20-27}, ...) met each 16-byte slot twice (SQ_LDS_BANK_CONFLICT = a third of the
+  // LDS cycles); with this 4 x 4 transpose every group covers all 64 banks for all three shifts (checked exhaustively
+  // against the group table).  The second pixel half is 16 pixels = 1024 bytes further (16 pixels do not change the
+  // swizzle term): a compile-time constant on the read
   int xsw16[C::HALO ? 3 : 1];
 #pragma unroll
   for (int dw = 0; dw < (C::HALO ? 3 : 1); ++dw) {
-    const int px = p16 + dw;
+    const int px = 4 * (p16 & 3) + (p16 >> 2) + dw;
     xsw16[dw] = (px * 4 + (kg ^ ((px >> 2) & 3))) * 16;
   }
 #pragma unroll
@@ -499,14 +503,14 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
         const int h = h0 + ws * MT + i;
         if (h >= H) continue;  // wave-uniform
         if constexpr (M16) {
-          // block (ph, nh), element e of lane (p16, kg): pixel 16 ph + 4 kg + e, channel 16 nh + p16
+          // block (ph, nh), element e of lane (p16, kg): MFMA row 4 kg + e = pixel 16 ph + 4 e + kg, channel 16 nh + p16
 #pragma unroll
           for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const int px = 16 * ph + 4 * kg + e;
+                const int px = 16 * ph + 4 * e + kg;
                 float v = acc4[j][i][q][ph][nh][e] + bias16[nh];
                 if (a.relu) v = fmaxf(v, 0.f);
                 scr[px * 33 + 16 * nh + p16] = v;
