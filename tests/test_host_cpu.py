@@ -237,3 +237,20 @@ def test_packed_clip_layouts_and_roi_align_host_logic():
         roi_align(torch.zeros(1, 8, 4, 4), torch.zeros(1, 5), 7, 1.0, 2)
     with pytest.raises(NotImplementedError):
         MultiScaleRoIAlign(['0'], 14, 0)
+
+
+def test_asm_mfma_kernels_pass_the_assembly_audit():
+    """The wide conv kernel and the 16x16x32 weight gradients issue their MFMAs as inline asm with a tied accumulator
+    (csrc/conv3d.hip, csrc/wgrad.hip); hipcc neither pads wait states around asm nor knows an MFMA sits inside, so what
+    the kernels rely on is checked on the compiler's gfx950 assembly (tools/diag/audit_asm_mfma.py): no scratch, every
+    accumulator tied, no other instruction on an accumulator register inside the MFMA loops, and the first readers
+    behind them separated by the kernels' s_nop pairs."""
+    import importlib.util
+    import shutil
+    if not (shutil.which('hipcc') or os.path.exists('/opt/rocm/bin/hipcc')):
+        pytest.skip('hipcc not available')
+    spec = importlib.util.spec_from_file_location('audit_asm_mfma', os.path.join(ROOT, 'tools', 'diag', 'audit_asm_mfma.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, bad = mod.main([])
+    assert n >= 20 and bad == 0
