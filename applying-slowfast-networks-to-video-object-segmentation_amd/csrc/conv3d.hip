@@ -20,8 +20,9 @@
 //   LDS images   : chunk-major [16B chunk][row][col] and [tap][chunk][n]: every ds_read_b128 of an
 //                  MFMA operand covers 32 consecutive 16-B slots per half-wave -> conflict-free.
 //   inner loop   : branch-free: per (tap, k-step) NT B-fragment + TT*MT A-fragment reads feed
-//                  TT*MT*NT MFMAs (32x32x16 bf16, or 4 x 32x32x2 exact f32); the reads of step k+1
-//                  are pinned ahead of the MFMAs of step k.
+//                  TT*MT*NT MFMAs (4 x 32x32x2 exact f32, 32x32x64 e4m3); the reads of step k+1
+//                  are pinned ahead of the MFMAs of step k.  bf16: 16x16x32 MFMAs, a tap = four
+//                  quadrant steps (pixel half, channel half) sharing operand sets -- see M16 below.
 //   epilogue     : + bias, optional += y, store as dtype, per-channel (sum, sumsq) of the tile
 //                  written as one deterministic partial row per workgroup (BN statistics).
 #include <stdlib.h>

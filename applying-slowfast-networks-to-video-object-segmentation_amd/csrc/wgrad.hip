@@ -8,6 +8,7 @@
 // [pixel][32 channels] (64-B rows) and are read with ds_read_b64_tr_b16 (hardware transpose: a
 // half-wave touches 4 consecutive 64-B rows = one 256-B bank row, conflict-free); f32: the exact
 // 32x32x2 MFMA takes one scalar per lane, read with ds_read_b32 (32 consecutive floats per half).
+// bf16 3x3 layers run 16x16x32 MFMAs with K = 32 pixels from two frames or two tile rows (FPR below).
 //
 // One workgroup (8 waves) owns NTN n-tiles x NTC c-tiles x DG temporal taps x all spatial taps;
 // wave = one (n-tile, c-tile, dt) group with TAPS accumulator tiles.  It sweeps its share of the
