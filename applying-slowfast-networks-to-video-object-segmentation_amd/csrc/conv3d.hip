@@ -814,6 +814,9 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
     };
     auto load_a = [&](int t) {
       const int dw = t / ROWS, rr = t - dw * ROWS;
+#ifdef SFVOS_FS_ABLATE  // timing-only builds: 1 = the pixel fragments of a stage are read once (t < PDA), 2 = the weight fragments once
+      if ((SFVOS_FS_ABLATE & 1) && t >= PDA) return;
+#endif
       if constexpr (F8) {
         av8[t % PDA] = read8(xfl + xsw8[0][dw] + rr * C::HC * 64, xfl + xsw8[1][dw] + rr * C::HC * 64);
       } else {
@@ -821,6 +824,21 @@ __device__ __forceinline__ void fs_body(const ConvArgs& a, const int wg, const C
       }
     };
     auto load_b = [&](int dw) {
+#ifdef SFVOS_FS_ABLATE
+      if ((SFVOS_FS_ABLATE & 2) && dw > 0) {   // (real values in both buffers: a zero or undefined operand would falsify the power)
+        if (dw == 1) {
+#pragma unroll
+          for (int dh = 0; dh < 3; ++dh) {
+            if constexpr (F8) bw8[1][dh] = bw8[0][dh];
+            else {
+#pragma unroll
+              for (int nh = 0; nh < NH; ++nh) bw[1][dh][nh] = bw[0][dh][nh];
+            }
+          }
+        }
+        return;
+      }
+#endif
 #pragma unroll
       for (int dh = 0; dh < 3; ++dh) {
         if constexpr (F8) {
