@@ -261,6 +261,13 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
     Copy cx, cd;
     // copy schedule by slot: x tile i = slot / NXP begins at slot i NXP, its pieces follow; then the dy frame
     auto copies = [&](int slot) {
+#ifdef SFVOS_WG_ABLATE
+      if ((SFVOS_WG_ABLATE & 4) && s > 0) {   // keep the cursors moving, copy nothing
+        if (slot < NXS * NXP) { if (slot % NXP == 0 && slot / NXP < nx) begin_x(cx); }
+        else if (slot < NCOPY && ndy && (slot - NXS * NXP) % NDY == 0) begin_dy(cd, s + 1, (slot - NXS * NXP) / NDY);
+        return;
+      }
+#endif
       if (slot < NXS * NXP) {
         const int i = slot / NXP, pc = slot - i * NXP;
         if (i < nx) {
@@ -312,6 +319,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
       static_assert(NCOPY <= NFR, "one copy slot per x fragment");
       u32x4 ar[3][2], br[C::PF + 1];
       auto load_a = [&](int ty) {
+#ifdef SFVOS_WG_ABLATE  // timing-only builds (wrong results): 1 = x fragments read PF + 1 times per stage, 2 = dy fragments three
+        if ((SFVOS_WG_ABLATE & 2) && ty >= 3) return;   // times, 4 = no staging copies behind the first stage
+#endif
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh) {
           const int y = (nh ? ya ^ 32 : ya) + ty * 16 * C::ROWB;
@@ -319,6 +329,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
         }
       };
       auto load_b = [&](int f) {
+#ifdef SFVOS_WG_ABLATE
+        if ((SFVOS_WG_ABLATE & 1) && f > C::PF) return;
+#endif
         const int rr = f / 6, ch = (f / 3) & 1, dw = f % 3;
         const int rb = rr * C::HC + dw, v = rb & 3, flip = ((rb >> 2) & 1) ^ ch;   // row base of the fragment
         br[f % (C::PF + 1)] = join(tr_read(smem + (flip ? xa[0][v] ^ 32 : xa[0][v]) + rb * C::ROWB),
