@@ -489,6 +489,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a) {
       // not yet copied (start of the sweep, or a tile boundary the ring could not prefetch across): every wave
       // is done with the previous stage after this barrier, so the slots of its frames may be overwritten
       if (s > 0) __syncthreads();
+#ifdef SFVOS_WG_ABLATE   // 8: the refill at a tile boundary copies nothing (cursors move)
+      if ((SFVOS_WG_ABLATE & 8) && s > 0) { while (xi_q <= need) { Copy c; begin_x(c); } } else
+#endif
       while (xi_q <= need) load_x_now();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
