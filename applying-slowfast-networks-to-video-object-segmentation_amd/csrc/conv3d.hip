@@ -494,7 +494,7 @@ __device__ __forceinline__ void conv3d_body(const ConvArgs& a) {
     if (nbase >= a.c_out) continue;  // wave-uniform
     const float bias = a.bias ? a.bias[nbase + r] : 0.f;
     const float desc = F8 ? a.bias[a.c_out + nbase + r] : 1.f;  // e4m3: [2][c_out] = (bias, de-quantisation factor)
-    const float bias16[2] = {a.bias ? a.bias[nbase + p16] : 0.f, a.bias ? a.bias[nbase + 16 + p16] : 0.f};
+    const float bias16[2] = {M16 && a.bias ? a.bias[nbase + p16] : 0.f, M16 && a.bias ? a.bias[nbase + 16 + p16] : 0.f};
 #pragma unroll
     for (int j = 0; j < TT; ++j) {
       const int to = tb0 + j;
